@@ -1,0 +1,143 @@
+// Shared host/device helpers for libgraphop_hip (gfx950 / CDNA4 only, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "graphop_hip.h"
+
+namespace graphop {
+
+using i64 = long long;  // same width as int64_t; HIP atomics are declared on (unsigned) long long
+
+// ---- error reporting (thread-local message, C ABI returns a code) ------------------------------
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* get_error();
+
+#define GO_CHECK_ARG(cond, ...)                \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::graphop::set_error(__VA_ARGS__);       \
+      return GRAPHOP_ERR_INVALID_ARGUMENT;     \
+    }                                          \
+  } while (0)
+
+#define GO_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::graphop::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                     \
+      return GRAPHOP_ERR_HIP;                                                             \
+    }                                                                                     \
+  } while (0)
+
+#define GO_LAUNCH_CHECK() GO_HIP(hipGetLastError())
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
+
+// ---- plan (host view) ---------------------------------------------------------------------------
+struct PlanStats {  // device-resident while the analysis kernels run, then copied back
+  i64 unsorted;          // #positions with row[c] < row[c-1]
+  i64 bad_indptr;        // #positions with indptr[c] > indptr[c+1] or out of [0, E]
+  i64 eid_not_identity;  // #k with eid[k] != k
+  i64 bad_eid;           // #k with eid[k] outside [0, E)
+  i64 bad_index;         // #k with indices[k] outside [0, bound)
+  i64 max_row;
+  i64 max_index;
+  i64 max_seg_len;
+  i64 n_segments;
+};
+
+}  // namespace graphop
+
+struct graphop_plan {
+  graphop_plan_info_t info;
+  const int64_t* row;      // identity of the arrays the plan was built from (not owned)
+  const int64_t* indptr;
+  const int64_t* eid;
+  const int64_t* indices;
+  int64_t* seg_chunk;      // [n_segments + 1] first chunk of each segment, then n_chunks (owned)
+  int32_t* idx32;          // [n_edges] (owned, optional)
+  int32_t* eid32;          // [n_edges] (owned, optional; NULL when eid is the identity)
+  int device;
+};
+
+// ---- device-side helpers ------------------------------------------------------------------------
+#ifdef __HIPCC__
+namespace graphop {
+
+constexpr int kWave = 64;
+
+// DPP lane movement inside a 16-lane row (no LDS traffic).  ctrl: 0xB1 = quad_perm[1,0,3,2],
+// 0x4E = quad_perm[2,3,0,1], 0x141 = row_half_mirror, 0x140 = row_mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over aligned groups of G lanes (G = 1..64, power of two); every lane gets the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (G >= 2) v += dpp_f32<0xB1>(v);
+  if constexpr (G >= 4) v += dpp_f32<0x4E>(v);
+  if constexpr (G >= 8) v += dpp_f32<0x141>(v);
+  if constexpr (G >= 16) v += dpp_f32<0x140>(v);
+  if constexpr (G >= 32) v += __shfl_xor(v, 16);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ float group_sum_rt(float v, int g) {  // g wave-uniform
+  switch (g) {
+    case 2: return group_sum<2>(v);
+    case 4: return group_sum<4>(v);
+    case 8: return group_sum<8>(v);
+    case 16: return group_sum<16>(v);
+    case 32: return group_sum<32>(v);
+    case 64: return group_sum<64>(v);
+    default: return v;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+// Float max through integer atomics (no CAS loop): non-negative floats order like ints,
+// negative floats order inversely as unsigned.
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_float(double* addr, double v) {
+  if (v >= 0.0)
+    atomicMax(reinterpret_cast<long long*>(addr), __double_as_longlong(v));
+  else
+    atomicMin(reinterpret_cast<unsigned long long*>(addr),
+              static_cast<unsigned long long>(__double_as_longlong(v)));
+}
+
+__device__ __forceinline__ float exp_t(float x) { return expf(x); }
+__device__ __forceinline__ double exp_t(double x) { return exp(x); }
+
+}  // namespace graphop
+#endif  // __HIPCC__

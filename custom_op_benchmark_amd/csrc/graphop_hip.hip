@@ -1,0 +1,598 @@
+// libgraphop_hip: C ABI (include/graphop_hip.h) over the gfx950 kernels.
+// Host-side dispatch only: validates sizes, zero-fills outputs (the reference returns at::zeros
+// tensors, graphop_kernel.cu:284,379-380,429,482,527,571-572) and picks fast fp32 vs generic.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels_fast.h"
+#include "kernels_generic.h"
+
+namespace graphop {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ---- optional per-kernel timing (hipEvents on the launch stream; off by default) -----------------
+struct ProfRec { const char* name; hipEvent_t t0, t1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+struct ProfScope {  // brackets one kernel launch with two events when profiling is enabled
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipStream_t st;
+  const char* name;
+  ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) { t0 = nullptr; return; }
+    (void)hipEventRecord(t0, st);
+  }
+  ~ProfScope() {
+    if (!t0) return;
+    (void)hipEventRecord(t1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({name, t0, t1});
+  }
+};
+
+int partition_count(const i64*, i64, i64, i64*, hipStream_t);
+int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_t);
+int plan_build(graphop_plan*, i64, hipStream_t);
+
+namespace {
+
+struct Tuning {
+  int sddmm_cpg;  // chunks per lane-group, SDDMM-type kernels
+  int spmm_cpg;   // chunks per lane-group, SpMM-type kernels
+  int force_generic;
+  Tuning() {
+    sddmm_cpg = env_int("GRAPHOP_SDDMM_CPG", 8);
+    spmm_cpg = env_int("GRAPHOP_SPMM_CPG", 16);
+    force_generic = env_int("GRAPHOP_FORCE_GENERIC", 0);
+    if (sddmm_cpg < 1) sddmm_cpg = 1;
+    if (spmm_cpg < 1) spmm_cpg = 1;
+  }
+};
+const Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+
+inline size_t esize(int dtype) { return dtype == GRAPHOP_F64 ? 8 : 4; }
+
+inline bool pow2(i64 v) { return v > 0 && (v & (v - 1)) == 0; }
+
+inline unsigned blocks_for(i64 work, i64 per_block) {
+  i64 b = ceil_div(work > 0 ? work : 1, per_block);
+  return (unsigned)b;
+}
+
+// fast fp32 path applies when a node row is 16..1024 floats (power of two), ids fit 32 bits
+inline bool fast_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_src_rows) {
+  if (tuning().force_generic || dtype != GRAPHOP_F32) return false;
+  const i64 F = h * d;
+  if (d % 4 != 0 || !pow2(F) || F < 16 || F > 1024 || !pow2(h)) return false;
+  if (n_edges >= 0x7fffffffLL || n_src_rows >= 0x7fffffffLL) return false;
+  return true;
+}
+
+#define GO_DISPATCH_LNV(F, ...)                                      \
+  switch (F) {                                                       \
+    case 16: { constexpr int L = 4, NV = 1; __VA_ARGS__; } break;    \
+    case 32: { constexpr int L = 8, NV = 1; __VA_ARGS__; } break;    \
+    case 64: { constexpr int L = 16, NV = 1; __VA_ARGS__; } break;   \
+    case 128: { constexpr int L = 32, NV = 1; __VA_ARGS__; } break;  \
+    case 256: { constexpr int L = 64, NV = 1; __VA_ARGS__; } break;  \
+    case 512: { constexpr int L = 64, NV = 2; __VA_ARGS__; } break;  \
+    case 1024: { constexpr int L = 64, NV = 4; __VA_ARGS__; } break; \
+    default: break;                                                  \
+  }
+
+// ---- launch helpers -------------------------------------------------------------------------------
+template <bool EDGE_B>
+int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
+                 const i64* indices, const void* A, const void* B, void* y, i64 C, i64 E,
+                 i64 n_src_rows, i64 h, i64 d, hipStream_t st) {
+  if (C == 0) return GRAPHOP_OK;
+  ProfScope prof(tag, st);
+  // EDGE_B (node_mul_edge): B rows are d wide, A rows h*d wide -> fast path only for h == 1
+  if (fast_ok(dtype, h, d, E, n_src_rows) && (!EDGE_B || h == 1)) {
+    const int cpg = tuning().sddmm_cpg;
+    const int F = (int)(h * d), d4 = (int)(d / 4);
+    GO_DISPATCH_LNV(F, {
+      const i64 groups = ceil_div(C, cpg);
+      const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
+      if (h == 1)
+        hipLaunchKernelGGL((k_sddmm_f32<L, NV, true, EDGE_B>), dim3(nb), dim3(kFastBlock), 0, st,
+                           row, indptr, eid, indices, (const float*)A, (const float*)B, (float*)y,
+                           C, (int)h, d4, cpg);
+      else if constexpr (!EDGE_B)
+        hipLaunchKernelGGL((k_sddmm_f32<L, NV, false, false>), dim3(nb), dim3(kFastBlock), 0, st,
+                           row, indptr, eid, indices, (const float*)A, (const float*)B, (float*)y,
+                           C, (int)h, d4, cpg);
+    });
+  } else {
+    const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
+    if (dtype == GRAPHOP_F32)
+      hipLaunchKernelGGL((k_sddmm_generic<float, EDGE_B>), dim3(nb), dim3(kGenericBlock), 0, st,
+                         row, indptr, eid, indices, (const float*)A, (const float*)B, (float*)y, C,
+                         h, d);
+    else
+      hipLaunchKernelGGL((k_sddmm_generic<double, EDGE_B>), dim3(nb), dim3(kGenericBlock), 0, st,
+                         row, indptr, eid, indices, (const double*)A, (const double*)B, (double*)y,
+                         C, h, d);
+  }
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+template <bool EDGE_X>
+int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
+                const i64* indices, const void* w, const void* X, void* out, i64 C, i64 E,
+                i64 n_src_rows, i64 h, i64 d, hipStream_t st) {
+  if (C == 0) return GRAPHOP_OK;
+  ProfScope prof(tag, st);
+  if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
+    const int cpg = tuning().spmm_cpg;
+    const int F = (int)(h * d), d4 = (int)(d / 4);
+    GO_DISPATCH_LNV(F, {
+      const i64 groups = ceil_div(C, cpg);
+      const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
+      if (h == 1)
+        hipLaunchKernelGGL((k_spmm_f32<L, NV, true>), dim3(nb), dim3(kFastBlock), 0, st, row,
+                           indptr, eid, indices, (const float*)w, (const float*)X, (float*)out, C,
+                           (int)h, d4, cpg);
+      else
+        hipLaunchKernelGGL((k_spmm_f32<L, NV, false>), dim3(nb), dim3(kFastBlock), 0, st, row,
+                           indptr, eid, indices, (const float*)w, (const float*)X, (float*)out, C,
+                           (int)h, d4, cpg);
+    });
+  } else {
+    const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
+    if (dtype == GRAPHOP_F32)
+      hipLaunchKernelGGL((k_spmm_generic<float, EDGE_X>), dim3(nb), dim3(kGenericBlock), 0, st,
+                         row, indptr, eid, indices, (const float*)w, (const float*)X, (float*)out,
+                         C, h, d);
+    else
+      hipLaunchKernelGGL((k_spmm_generic<double, EDGE_X>), dim3(nb), dim3(kGenericBlock), 0, st,
+                         row, indptr, eid, indices, (const double*)w, (const double*)X,
+                         (double*)out, C, h, d);
+  }
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+inline bool plan_matches(const graphop_plan* p, const i64* row, const i64* indptr, const i64* eid,
+                         i64 C, i64 E) {
+  return p && p->row == (const int64_t*)row && p->indptr == (const int64_t*)indptr &&
+         p->eid == (const int64_t*)eid && p->info.n_chunks == C && p->info.n_edges == E;
+}
+
+inline int seg_group_width(i64 items_per_seg, i64 h) {
+  int g = items_per_seg >= 48 ? 64 : items_per_seg >= 24 ? 32 : items_per_seg >= 12 ? 16 : 8;
+  while (g < h) g <<= 1;
+  return g;
+}
+
+template <typename T, bool BWD>
+int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid, const T* in0,
+                       const T* in1, T* out, i64 h, hipStream_t st) {
+  const i64 S = p->info.n_segments;
+  if (S == 0) return GRAPHOP_OK;
+  ProfScope prof(BWD ? "softmax_bwd" : "softmax_fwd", st);
+  const bool id = p->info.eid_identity != 0;
+  if (pow2(h) && h <= 64) {
+    const int G = seg_group_width(p->info.n_edges * h / S, h);
+    const unsigned nb = blocks_for(S, kFastBlock / G);
+#define GO_SEG(GW, ID)                                                                           \
+  if constexpr (!BWD)                                                                            \
+    hipLaunchKernelGGL((k_softmax_fwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
+                       (const i64*)p->seg_chunk, indptr, eid, in0, out, S, (int)h);              \
+  else                                                                                           \
+    hipLaunchKernelGGL((k_softmax_bwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
+                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, (int)h);
+#define GO_SEG_ID(GW) if (id) { GO_SEG(GW, true) } else { GO_SEG(GW, false) }
+    switch (G) {
+      case 8: GO_SEG_ID(8) break;
+      case 16: GO_SEG_ID(16) break;
+      case 32: GO_SEG_ID(32) break;
+      default: GO_SEG_ID(64) break;
+    }
+#undef GO_SEG_ID
+#undef GO_SEG
+  } else {
+    const unsigned nb = blocks_for(S, kFastBlock / kWave);
+    hipLaunchKernelGGL((k_softmax_seg_anyh<T, BWD>), dim3(nb), dim3(kFastBlock), 0, st,
+                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, h);
+  }
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+template <typename T>
+int softmax_forward_t(const i64* row, const i64* indptr, const i64* eid, const T* x, T* y, i64 C,
+                      i64 E, i64 h, T* ws, i64 ws_rows, const graphop_plan* plan, hipStream_t st) {
+  const bool owned = plan_matches(plan, row, indptr, eid, C, E) && plan->info.row_owned;
+  const bool covered = owned && plan->info.full_coverage && plan->info.eid_identity;
+  if (!covered && E * h > 0) GO_HIP(hipMemsetAsync(y, 0, sizeof(T) * (size_t)(E * h), st));
+  if (C == 0) return GRAPHOP_OK;
+  if (owned) return launch_softmax_seg<T, false>(plan, indptr, eid, x, (const T*)nullptr, y, h, st);
+  GO_CHECK_ARG(ws != nullptr && ws_rows > 0,
+               "sparse_softmax_forward: the general (plan-less) path needs a workspace of "
+               "2*workspace_rows*h values with workspace_rows > max(row)");
+  T* max_val = ws;
+  T* sum = ws + ws_rows * h;
+  const unsigned fb = (unsigned)ceil_div(ws_rows * h, 256) > 4096u ? 4096u
+                                                                   : (unsigned)ceil_div(ws_rows * h, 256);
+  hipLaunchKernelGGL((k_fill<T>), dim3(fb), dim3(256), 0, st, max_val, ws_rows * h, (T)-1e9);
+  GO_HIP(hipMemsetAsync(sum, 0, sizeof(T) * (size_t)(ws_rows * h), st));
+  const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
+  hipLaunchKernelGGL((k_softmax_max<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr, eid, x,
+                     max_val, C, h);
+  hipLaunchKernelGGL((k_softmax_exp_sum<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr,
+                     eid, x, (const T*)max_val, sum, y, C, h);
+  hipLaunchKernelGGL((k_softmax_norm<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr, eid,
+                     (const T*)sum, y, C, h);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+template <typename T>
+int softmax_backward_t(const i64* row, const i64* indptr, const i64* eid, const T* y, const T* dy,
+                       T* dx, i64 C, i64 E, i64 h, T* ws, i64 ws_rows, const graphop_plan* plan,
+                       hipStream_t st) {
+  const bool owned = plan_matches(plan, row, indptr, eid, C, E) && plan->info.row_owned;
+  const bool covered = owned && plan->info.full_coverage && plan->info.eid_identity;
+  if (!covered && E * h > 0) GO_HIP(hipMemsetAsync(dx, 0, sizeof(T) * (size_t)(E * h), st));
+  if (C == 0) return GRAPHOP_OK;
+  if (owned) return launch_softmax_seg<T, true>(plan, indptr, eid, y, dy, dx, h, st);
+  GO_CHECK_ARG(ws != nullptr && ws_rows > 0,
+               "sparse_softmax_backward: the general (plan-less) path needs a workspace of "
+               "workspace_rows*h values with workspace_rows > max(row)");
+  GO_HIP(hipMemsetAsync(ws, 0, sizeof(T) * (size_t)(ws_rows * h), st));
+  const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
+  hipLaunchKernelGGL((k_softmax_bwd_aggre<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr,
+                     eid, dy, y, ws, C, h);
+  hipLaunchKernelGGL((k_softmax_bwd_dx<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr, eid,
+                     dy, y, (const T*)ws, dx, C, h);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+inline int check_common(const char* fn, int dtype, i64 C, i64 E, i64 h, i64 d) {
+  GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: dtype must be GRAPHOP_F32 or "
+               "GRAPHOP_F64", fn);
+  GO_CHECK_ARG(C >= 0 && E >= 0 && h >= 1 && d >= 0, "%s: negative size (n_chunks=%lld n_edges=%lld "
+               "h=%lld d=%lld)", fn, (long long)C, (long long)E, (long long)h, (long long)d);
+  return GRAPHOP_OK;
+}
+
+#define GO_PTR(fn, p) GO_CHECK_ARG((p) != nullptr, "%s: " #p " is NULL", fn)
+#define GO_TRY(expr)                     \
+  do {                                   \
+    int _rc = (expr);                    \
+    if (_rc != GRAPHOP_OK) return _rc;   \
+  } while (0)
+
+}  // namespace
+}  // namespace graphop
+
+using namespace graphop;
+
+extern "C" {
+
+int graphop_abi_version(void) { return GRAPHOP_ABI_VERSION; }
+const char* graphop_last_error(void) { return get_error(); }
+
+int graphop_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return GRAPHOP_OK;
+}
+
+// Synchronises the recorded events, aggregates per tag, clears the log.  Writes up to `cap`
+// records; returns the number of distinct tags (or -1 on error).
+int graphop_profile_read(graphop_profile_rec_t* out, int cap) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::map<std::string, graphop_profile_rec_t> agg;
+  std::vector<std::string> order;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.t1) != hipSuccess || hipEventElapsedTime(&ms, r.t0, r.t1) != hipSuccess) {
+      set_error("profile_read: event query failed");
+      return -1;
+    }
+    (void)hipEventDestroy(r.t0);
+    (void)hipEventDestroy(r.t1);
+    auto it = agg.find(r.name);
+    if (it == agg.end()) {
+      graphop_profile_rec_t rec;
+      memset(&rec, 0, sizeof(rec));
+      strncpy(rec.name, r.name, sizeof(rec.name) - 1);
+      rec.min_ms = ms;
+      it = agg.emplace(r.name, rec).first;
+      order.push_back(r.name);
+    }
+    it->second.calls += 1;
+    it->second.total_ms += ms;
+    if (ms < it->second.min_ms) it->second.min_ms = ms;
+    if (ms > it->second.max_ms) it->second.max_ms = ms;
+  }
+  g_prof.clear();
+  int n = 0;
+  for (auto& k : order) {
+    if (out && n < cap) out[n] = agg[k];
+    ++n;
+  }
+  return n;
+}
+
+int graphop_partition_csr_count(const int64_t* indptr, int64_t n_rows, int64_t chunk_size,
+                                int64_t* first_chunk, void* stream) {
+  GO_CHECK_ARG(indptr && first_chunk, "partition_csr_count: NULL pointer");
+  GO_CHECK_ARG(n_rows >= 0 && n_rows < 0x7ffffffeLL, "partition_csr_count: n_rows out of range");
+  GO_CHECK_ARG(chunk_size >= 1, "partition_csr_count: chunk_size must be >= 1");
+  return partition_count((const i64*)indptr, n_rows, chunk_size, (i64*)first_chunk,
+                         (hipStream_t)stream);
+}
+
+int graphop_partition_csr_fill(const int64_t* indptr, const int64_t* first_chunk, int64_t n_rows,
+                               int64_t chunk_size, int64_t n_chunks, int64_t* row,
+                               int64_t* indptr_out, void* stream) {
+  GO_CHECK_ARG(indptr && first_chunk && indptr_out && (row || n_chunks == 0),
+               "partition_csr_fill: NULL pointer");
+  GO_CHECK_ARG(n_rows >= 0 && n_chunks >= 0 && chunk_size >= 1, "partition_csr_fill: bad size");
+  return partition_fill((const i64*)indptr, (const i64*)first_chunk, n_rows, chunk_size, n_chunks,
+                        (i64*)row, (i64*)indptr_out, (hipStream_t)stream);
+}
+
+int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                        const int64_t* indices, int64_t n_chunks, int64_t n_edges,
+                        int64_t n_index_bound, void* stream, graphop_plan_t** plan_out) {
+  GO_CHECK_ARG(plan_out != nullptr, "plan_create: plan_out is NULL");
+  *plan_out = nullptr;
+  GO_CHECK_ARG(indptr != nullptr && (row != nullptr || n_chunks == 0) &&
+               (eid != nullptr || n_edges == 0), "plan_create: NULL pointer");
+  GO_CHECK_ARG(n_chunks >= 0 && n_chunks < 0x7fffffffLL && n_edges >= 0,
+               "plan_create: size out of range");
+  graphop_plan* p = (graphop_plan*)calloc(1, sizeof(graphop_plan));
+  GO_CHECK_ARG(p != nullptr, "plan_create: out of host memory");
+  p->row = row; p->indptr = indptr; p->eid = eid; p->indices = indices;
+  p->info.n_chunks = n_chunks;
+  p->info.n_edges = n_edges;
+  (void)hipGetDevice(&p->device);
+  const int rc = plan_build(p, n_index_bound, (hipStream_t)stream);
+  if (rc != GRAPHOP_OK) {
+    graphop_plan_destroy(p);
+    return rc;
+  }
+  *plan_out = p;
+  return GRAPHOP_OK;
+}
+
+int graphop_plan_info(const graphop_plan_t* plan, graphop_plan_info_t* info_out) {
+  GO_CHECK_ARG(plan && info_out, "plan_info: NULL pointer");
+  *info_out = plan->info;
+  return GRAPHOP_OK;
+}
+
+void graphop_plan_destroy(graphop_plan_t* plan) {
+  if (!plan) return;
+  if (plan->seg_chunk) (void)hipFree(plan->seg_chunk);
+  if (plan->idx32) (void)hipFree(plan->idx32);
+  if (plan->eid32) (void)hipFree(plan->eid32);
+  free(plan);
+}
+
+int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                 const int64_t* eid, const int64_t* indices, const void* A,
+                                 const void* B, void* y, int64_t n_chunks, int64_t n_edges,
+                                 int64_t n_a, int64_t n_b, int64_t h, int64_t d,
+                                 const graphop_plan_t* plan, void* stream) {
+  const char* fn = "maskedmm_csr_forward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_edges * h == 0) return GRAPHOP_OK;
+  GO_PTR(fn, y);
+  const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                    n_chunks, n_edges) &&
+                       plan->info.full_coverage && plan->info.eid_identity &&
+                       plan->info.indptr_monotone;
+  if (!covered) GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
+  if (n_chunks == 0) return GRAPHOP_OK;
+  GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, A); GO_PTR(fn, B);
+  (void)n_a;
+  return launch_sddmm<false>("sddmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                             (const i64*)indices, A, B, y, n_chunks, n_edges, n_b, h, d, st);
+}
+
+int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
+                                  const int64_t* eid_r, const int64_t* indices_r,
+                                  const int64_t* col, const int64_t* indptr_c,
+                                  const int64_t* eid_c, const int64_t* indices_c, const void* A,
+                                  const void* B, const void* dy, void* dA, void* dB,
+                                  int64_t n_row_chunks, int64_t n_col_chunks, int64_t n_edges,
+                                  int64_t n_a, int64_t n_b, int64_t h, int64_t d,
+                                  const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
+                                  void* stream) {
+  const char* fn = "maskedmm_csr_backward";
+  GO_TRY(check_common(fn, dtype, n_row_chunks, n_edges, h, d));
+  GO_CHECK_ARG(n_col_chunks >= 0 && n_a >= 0 && n_b >= 0, "%s: negative size", fn);
+  hipStream_t st = (hipStream_t)stream;
+  (void)plan_r; (void)plan_c;
+  const size_t es = esize(dtype);
+  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
+  if (n_b * h * d > 0) { GO_PTR(fn, dB); GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_b * h * d), st)); }
+  if (h * d == 0) return GRAPHOP_OK;
+  if (n_row_chunks > 0) {
+    GO_PTR(fn, row); GO_PTR(fn, indptr_r); GO_PTR(fn, eid_r); GO_PTR(fn, indices_r); GO_PTR(fn, B); GO_PTR(fn, dy);
+    GO_TRY(launch_spmm<false>("sddmm_bwd_dA", dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r,
+                              (const i64*)indices_r, dy, B, dA, n_row_chunks, n_edges, n_b, h, d, st));
+  }
+  if (n_col_chunks > 0) {
+    GO_PTR(fn, col); GO_PTR(fn, indptr_c); GO_PTR(fn, eid_c); GO_PTR(fn, indices_c); GO_PTR(fn, A); GO_PTR(fn, dy);
+    GO_TRY(launch_spmm<false>("sddmm_bwd_dB", dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
+                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, st));
+  }
+  return GRAPHOP_OK;
+}
+
+int graphop_sparse_softmax_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                   const int64_t* eid, const void* x, void* y, int64_t n_chunks,
+                                   int64_t n_edges, int64_t h, void* workspace,
+                                   int64_t workspace_rows, const graphop_plan_t* plan,
+                                   void* stream) {
+  const char* fn = "sparse_softmax_forward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, 0));
+  if (n_edges * h == 0) return GRAPHOP_OK;
+  GO_PTR(fn, y);
+  if (n_chunks > 0) { GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, x); }
+  if (dtype == GRAPHOP_F32)
+    return softmax_forward_t<float>((const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                    (const float*)x, (float*)y, n_chunks, n_edges, h,
+                                    (float*)workspace, workspace_rows, plan, (hipStream_t)stream);
+  return softmax_forward_t<double>((const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                   (const double*)x, (double*)y, n_chunks, n_edges, h,
+                                   (double*)workspace, workspace_rows, plan, (hipStream_t)stream);
+}
+
+int graphop_sparse_softmax_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                    const int64_t* eid, const void* y, const void* dy, void* dx,
+                                    int64_t n_chunks, int64_t n_edges, int64_t h,
+                                    void* workspace, int64_t workspace_rows,
+                                    const graphop_plan_t* plan, void* stream) {
+  const char* fn = "sparse_softmax_backward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, 0));
+  if (n_edges * h == 0) return GRAPHOP_OK;
+  GO_PTR(fn, dx);
+  if (n_chunks > 0) { GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, y); GO_PTR(fn, dy); }
+  if (dtype == GRAPHOP_F32)
+    return softmax_backward_t<float>((const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                     (const float*)y, (const float*)dy, (float*)dx, n_chunks,
+                                     n_edges, h, (float*)workspace, workspace_rows, plan,
+                                     (hipStream_t)stream);
+  return softmax_backward_t<double>((const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                    (const double*)y, (const double*)dy, (double*)dx, n_chunks,
+                                    n_edges, h, (double*)workspace, workspace_rows, plan,
+                                    (hipStream_t)stream);
+}
+
+int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                const int64_t* eid, const int64_t* indices, const void* edata,
+                                const void* x, void* y, int64_t n_chunks, int64_t n_edges,
+                                int64_t n_x, int64_t n_y, int64_t h, int64_t d,
+                                const graphop_plan_t* plan, void* stream) {
+  const char* fn = "vector_spmm_forward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
+  GO_CHECK_ARG(n_x >= 0 && n_y >= 0, "%s: negative size", fn);
+  hipStream_t st = (hipStream_t)stream;
+  (void)plan;
+  if (n_y * h * d == 0) return GRAPHOP_OK;
+  GO_PTR(fn, y);
+  GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_y * h * d), st));
+  if (n_chunks == 0) return GRAPHOP_OK;
+  GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, edata); GO_PTR(fn, x);
+  return launch_spmm<false>("spmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                            (const i64*)indices, edata, x, y, n_chunks, n_edges, n_x, h, d, st);
+}
+
+int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                 const int64_t* eid, const int64_t* indices, const int64_t* col,
+                                 const int64_t* indptr_t, const int64_t* eid_t,
+                                 const int64_t* indices_t, const void* edata, const void* dy,
+                                 const void* x, void* dedata, void* dx, int64_t n_row_chunks,
+                                 int64_t n_col_chunks, int64_t n_edges, int64_t n_x, int64_t n_dy,
+                                 int64_t h, int64_t d, const graphop_plan_t* plan_r,
+                                 const graphop_plan_t* plan_c, void* stream) {
+  const char* fn = "vector_spmm_backward";
+  GO_TRY(check_common(fn, dtype, n_row_chunks, n_edges, h, d));
+  GO_CHECK_ARG(n_col_chunks >= 0 && n_x >= 0 && n_dy >= 0, "%s: negative size", fn);
+  hipStream_t st = (hipStream_t)stream;
+  (void)plan_c;
+  const size_t es = esize(dtype);
+  if (n_edges * h > 0) {
+    GO_PTR(fn, dedata);
+    const bool covered = plan_matches(plan_r, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                      n_row_chunks, n_edges) &&
+                         plan_r->info.full_coverage && plan_r->info.eid_identity &&
+                         plan_r->info.indptr_monotone;
+    if (!covered) GO_HIP(hipMemsetAsync(dedata, 0, es * (size_t)(n_edges * h), st));
+  }
+  if (n_x * h * d > 0) { GO_PTR(fn, dx); GO_HIP(hipMemsetAsync(dx, 0, es * (size_t)(n_x * h * d), st)); }
+  if (h * d == 0) return GRAPHOP_OK;
+  if (n_row_chunks > 0 && n_edges > 0) {
+    GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, dy); GO_PTR(fn, x);
+    // kernel_0: dedata = SDDMM(dy, x) over the row-major CSR (graphop_kernel.cu:135-149)
+    GO_TRY(launch_sddmm<false>("spmm_bwd_dedata", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                               (const i64*)indices, dy, x, dedata, n_row_chunks, n_edges, n_x, h, d, st));
+  }
+  if (n_col_chunks > 0) {
+    GO_PTR(fn, col); GO_PTR(fn, indptr_t); GO_PTR(fn, eid_t); GO_PTR(fn, indices_t); GO_PTR(fn, edata); GO_PTR(fn, dy);
+    // kernel_1: dx = SpMM(edata, dy) over the column-major CSR, all C' chunks (:151-163)
+    GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
+                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, st));
+  }
+  return GRAPHOP_OK;
+}
+
+int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                  const int64_t* eid, const void* A, const void* B, void* y,
+                                  int64_t n_chunks, int64_t n_edges, int64_t n_a, int64_t h,
+                                  int64_t d, const graphop_plan_t* plan, void* stream) {
+  const char* fn = "node_mul_edge_forward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
+  hipStream_t st = (hipStream_t)stream;
+  (void)plan; (void)n_a;
+  if (n_edges * h == 0) return GRAPHOP_OK;
+  GO_PTR(fn, y);
+  GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
+  if (n_chunks == 0) return GRAPHOP_OK;
+  GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B);
+  return launch_sddmm<true>("node_mul_edge_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                            (const i64*)eid, A, B, y, n_chunks, n_edges, n_edges, h, d, st);
+}
+
+int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                   const int64_t* eid, const void* A, const void* B,
+                                   const void* dy, void* dA, void* dB, int64_t n_chunks,
+                                   int64_t n_edges, int64_t n_a, int64_t h, int64_t d,
+                                   const graphop_plan_t* plan, void* stream) {
+  const char* fn = "node_mul_edge_backward";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
+  hipStream_t st = (hipStream_t)stream;
+  (void)plan;
+  const size_t es = esize(dtype);
+  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
+  if (n_edges * d > 0) { GO_PTR(fn, dB); GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_edges * d), st)); }
+  if (n_chunks == 0 || h * d == 0) return GRAPHOP_OK;
+  GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B); GO_PTR(fn, dy);
+  // kernel_0 (graphop_kernel.cu:61-73): dA[row] += sum_k dy[eid[k], j/d] * B[eid[k], j%d]
+  GO_TRY(launch_spmm<true>("node_mul_edge_bwd_dA", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                           (const i64*)eid, dy, B, dA, n_chunks, n_edges, n_edges, h, d, st));
+  // kernel_1 (:79-94): dB[eid[k], j] = sum_ki dy[eid[k], ki] * A[row, ki, j]
+  const unsigned nb = (unsigned)ceil_div(n_chunks, kGenericWavesPerBlock);
+  if (dtype == GRAPHOP_F32)
+    hipLaunchKernelGGL((k_node_mul_edge_bwd_b<float>), dim3(nb), dim3(kGenericBlock), 0, st,
+                       (const i64*)row, (const i64*)indptr, (const i64*)eid, (const float*)A,
+                       (const float*)dy, (float*)dB, n_chunks, h, d);
+  else
+    hipLaunchKernelGGL((k_node_mul_edge_bwd_b<double>), dim3(nb), dim3(kGenericBlock), 0, st,
+                       (const i64*)row, (const i64*)indptr, (const i64*)eid, (const double*)A,
+                       (const double*)dy, (double*)dB, n_chunks, h, d);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// Plan construction + partition_csr kernels (setup path; integer work, bit-exact).
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace graphop {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(i64 n, int block = kBlock, i64 cap = 1 << 20) {
+  i64 g = ceil_div(n > 0 ? n : 1, block);
+  return (unsigned)(g > cap ? cap : g);
+}
+
+// ---- partition_csr (part_csr.py:13-27) ----------------------------------------------------------
+__global__ void k_part_count(const i64* __restrict__ indptr, i64 n_rows, i64 chunk,
+                             i64* __restrict__ cnt) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; i <= n_rows; i += stride) {
+    i64 c = 0;
+    if (i < n_rows) {
+      const i64 deg = indptr[i + 1] - indptr[i];
+      c = deg > 0 ? (deg + chunk - 1) / chunk : 0;  // len(range(a, b, chunk))
+    }
+    cnt[i] = c;
+  }
+}
+
+__global__ void k_part_fill(const i64* __restrict__ indptr, const i64* __restrict__ first,
+                            i64 n_rows, i64 chunk, i64 n_chunks, i64* __restrict__ row,
+                            i64* __restrict__ out) {
+  i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  if (c == 0) out[n_chunks] = indptr[n_rows];  // indptr_.append(indptr[-1])
+  for (; c < n_chunks; c += stride) {
+    // owning row = last i with first[i] <= c (empty rows share their successor's value)
+    i64 lo = 0, hi = n_rows;  // invariant: first[lo] <= c < first[hi]
+    while (hi - lo > 1) {
+      const i64 mid = (lo + hi) >> 1;
+      if (first[mid] <= c) lo = mid; else hi = mid;
+    }
+    row[c] = lo;
+    out[c] = indptr[lo] + (c - first[lo]) * chunk;
+  }
+}
+
+// ---- plan analysis --------------------------------------------------------------------------------
+__global__ void k_plan_chunks(const i64* __restrict__ row, const i64* __restrict__ indptr,
+                              i64 n_chunks, i64 n_edges, int* __restrict__ head,
+                              PlanStats* __restrict__ st) {
+  i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  i64 unsorted = 0, bad = 0, mx = -1;
+  for (; c < n_chunks; c += stride) {
+    const i64 r = row[c];
+    const i64 rp = c > 0 ? row[c - 1] : -1;
+    head[c] = (c == 0 || r != rp) ? 1 : 0;
+    if (c > 0 && r < rp) ++unsorted;
+    if (r < 0) ++bad;
+    const i64 a = indptr[c], b = indptr[c + 1];
+    if (a > b || a < 0 || b > n_edges) ++bad;
+    mx = r > mx ? r : mx;
+  }
+  if (unsorted) atomicAdd((unsigned long long*)&st->unsorted, (unsigned long long)unsorted);
+  if (bad) atomicAdd((unsigned long long*)&st->bad_indptr, (unsigned long long)bad);
+  if (mx >= 0) atomicMax(&st->max_row, mx);
+}
+
+__global__ void k_plan_edges(const i64* __restrict__ eid, const i64* __restrict__ indices,
+                             i64 n_edges, i64 bound, PlanStats* __restrict__ st) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  i64 notid = 0, bad_e = 0, bad_i = 0, mx = -1;
+  for (; k < n_edges; k += stride) {
+    const i64 e = eid[k];
+    if (e != k) ++notid;
+    if (e < 0 || e >= n_edges) ++bad_e;
+    if (indices) {
+      const i64 v = indices[k];
+      if (v < 0 || (bound > 0 && v >= bound)) ++bad_i;
+      mx = v > mx ? v : mx;
+    }
+  }
+  if (notid) atomicAdd((unsigned long long*)&st->eid_not_identity, (unsigned long long)notid);
+  if (bad_e) atomicAdd((unsigned long long*)&st->bad_eid, (unsigned long long)bad_e);
+  if (bad_i) atomicAdd((unsigned long long*)&st->bad_index, (unsigned long long)bad_i);
+  if (mx >= 0) atomicMax(&st->max_index, mx);
+}
+
+__global__ void k_plan_fill_heads(const int* __restrict__ head, const i64* __restrict__ pos,
+                                  i64 n_chunks, i64* __restrict__ seg_chunk,
+                                  PlanStats* __restrict__ st) {
+  i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; c < n_chunks; c += stride) {
+    if (head[c]) seg_chunk[pos[c]] = c;
+    if (c == n_chunks - 1) {
+      const i64 ns = pos[c] + head[c];
+      seg_chunk[ns] = n_chunks;
+      st->n_segments = ns;
+    }
+  }
+}
+
+__global__ void k_plan_seg_len(const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+                               const PlanStats* __restrict__ st_in, PlanStats* __restrict__ st) {
+  const i64 ns = st_in->n_segments;
+  i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  i64 mx = 0;
+  for (; s < ns; s += stride) {
+    const i64 len = indptr[seg_chunk[s + 1]] - indptr[seg_chunk[s]];
+    mx = len > mx ? len : mx;
+  }
+  if (mx > 0) atomicMax(&st->max_seg_len, mx);
+}
+
+__global__ void k_narrow(const i64* __restrict__ src, int32_t* __restrict__ dst, i64 n) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (int32_t)src[i];
+}
+
+struct DevBuf {  // frees on scope exit (setup path only)
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+int partition_count(const i64* indptr, i64 n_rows, i64 chunk, i64* first, hipStream_t st) {
+  hipLaunchKernelGGL(k_part_count, dim3(grid_for(n_rows + 1)), dim3(kBlock), 0, st, indptr,
+                     n_rows, chunk, first);
+  GO_LAUNCH_CHECK();
+  size_t tmp_bytes = 0;
+  GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, first, first, (int)(n_rows + 1), st));
+  DevBuf tmp;
+  GO_HIP(hipMalloc(&tmp.p, tmp_bytes ? tmp_bytes : 16));
+  GO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, first, first, (int)(n_rows + 1), st));
+  GO_HIP(hipStreamSynchronize(st));  // tmp is freed on return
+  return GRAPHOP_OK;
+}
+
+int partition_fill(const i64* indptr, const i64* first, i64 n_rows, i64 chunk, i64 n_chunks,
+                   i64* row, i64* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_part_fill, dim3(grid_for(n_chunks)), dim3(kBlock), 0, st, indptr, first,
+                     n_rows, chunk, n_chunks, row, out);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
+  const i64 C = p->info.n_chunks, E = p->info.n_edges;
+  const i64* row = (const i64*)p->row;
+  const i64* indptr = (const i64*)p->indptr;
+  const i64* eid = (const i64*)p->eid;
+  const i64* indices = (const i64*)p->indices;
+
+  DevBuf d_stats, d_head, d_pos, d_tmp;
+  GO_HIP(hipMalloc(&d_stats.p, sizeof(PlanStats)));
+  PlanStats init;
+  memset(&init, 0, sizeof(init));
+  init.max_row = -1;
+  init.max_index = -1;
+  GO_HIP(hipMemcpyAsync(d_stats.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
+  PlanStats* stats = (PlanStats*)d_stats.p;
+
+  GO_HIP(hipMalloc((void**)&p->seg_chunk, sizeof(i64) * (size_t)(C + 1)));
+  if (C > 0) {
+    GO_HIP(hipMalloc(&d_head.p, sizeof(int) * (size_t)C));
+    GO_HIP(hipMalloc(&d_pos.p, sizeof(i64) * (size_t)C));
+    hipLaunchKernelGGL(k_plan_chunks, dim3(grid_for(C, kBlock, 4096)), dim3(kBlock), 0, st, row,
+                       indptr, C, E, (int*)d_head.p, stats);
+    GO_LAUNCH_CHECK();
+    size_t tmp_bytes = 0;
+    GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)d_head.p, (i64*)d_pos.p,
+                                            (int)C, st));
+    GO_HIP(hipMalloc(&d_tmp.p, tmp_bytes ? tmp_bytes : 16));
+    GO_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, (int*)d_head.p, (i64*)d_pos.p,
+                                            (int)C, st));
+    hipLaunchKernelGGL(k_plan_fill_heads, dim3(grid_for(C, kBlock, 4096)), dim3(kBlock), 0, st,
+                       (const int*)d_head.p, (const i64*)d_pos.p, C, (i64*)p->seg_chunk, stats);
+    GO_LAUNCH_CHECK();
+  } else {
+    const i64 zero = 0;
+    GO_HIP(hipMemcpyAsync(p->seg_chunk, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+  }
+  if (E > 0) {
+    hipLaunchKernelGGL(k_plan_edges, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, eid,
+                       indices, E, n_index_bound, stats);
+    GO_LAUNCH_CHECK();
+  }
+  PlanStats h;
+  GO_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+
+  graphop_plan_info_t& info = p->info;
+  info.n_segments = h.n_segments;
+  info.max_row = h.max_row;
+  info.max_index = h.max_index;
+  info.rows_sorted = h.unsorted == 0;
+  info.indptr_monotone = h.bad_indptr == 0;
+  info.eid_identity = h.eid_not_identity == 0;
+  info.row_owned = info.rows_sorted && info.indptr_monotone;
+  info.full_coverage = 0;
+  info.max_segment_len = 0;
+  info.has_idx32 = 0;
+
+  if (h.bad_indptr) {
+    set_error("plan: %lld chunk(s) with indptr[c] > indptr[c+1], indptr outside [0, n_edges] or "
+              "negative row id", (long long)h.bad_indptr);
+    return GRAPHOP_ERR_BAD_GRAPH;
+  }
+  if (h.bad_eid) {
+    set_error("plan: %lld eid value(s) outside [0, %lld)", (long long)h.bad_eid, (long long)E);
+    return GRAPHOP_ERR_BAD_GRAPH;
+  }
+  if (h.bad_index) {
+    set_error("plan: %lld indices value(s) outside [0, %lld)", (long long)h.bad_index,
+              (long long)n_index_bound);
+    return GRAPHOP_ERR_BAD_GRAPH;
+  }
+
+  if (C > 0) {
+    i64 ends[2];
+    GO_HIP(hipMemcpyAsync(&ends[0], indptr, sizeof(i64), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipMemcpyAsync(&ends[1], indptr + C, sizeof(i64), hipMemcpyDeviceToHost, st));
+    if (info.row_owned) {
+      hipLaunchKernelGGL(k_plan_seg_len, dim3(grid_for(h.n_segments, kBlock, 4096)), dim3(kBlock),
+                         0, st, (const i64*)p->seg_chunk, indptr, (const PlanStats*)stats, stats);
+      GO_LAUNCH_CHECK();
+    }
+    GO_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipStreamSynchronize(st));
+    info.full_coverage = ends[0] == 0 && ends[1] == E;
+    info.max_segment_len = h.max_seg_len;
+  } else {
+    info.full_coverage = E == 0;
+  }
+
+  // 32-bit mirrors of the slot arrays (halves index traffic of every pass)
+  const bool want32 = env_int("GRAPHOP_IDX32", 1) != 0;
+  if (want32 && E > 0 && E < 0x7fffffffLL && h.max_index < 0x7fffffffLL) {
+    if (indices) {
+      GO_HIP(hipMalloc((void**)&p->idx32, sizeof(int32_t) * (size_t)E));
+      hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, indices,
+                         p->idx32, E);
+      GO_LAUNCH_CHECK();
+    }
+    if (!info.eid_identity) {
+      GO_HIP(hipMalloc((void**)&p->eid32, sizeof(int32_t) * (size_t)E));
+      hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, eid,
+                         p->eid32, E);
+      GO_LAUNCH_CHECK();
+    }
+    GO_HIP(hipStreamSynchronize(st));
+    info.has_idx32 = 1;
+  }
+  return GRAPHOP_OK;
+}
+
+}  // namespace graphop

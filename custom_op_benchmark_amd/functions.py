@@ -1,0 +1,87 @@
+"""autograd glue: the reference's four ``torch.autograd.Function`` classes.
+
+Same class names, ``.apply`` argument orders and gradient routing as ``wrapper.py:8-55``: index
+tensors get ``None`` gradients; ``MaskedMMCSR`` returns ``(dA, dB)`` last, ``VectorSPMM``
+``(dedata, dx)`` last, ``SparseSoftmax`` a 4-tuple, ``NodeMulEdge`` a 5-tuple.  They call this
+package's HIP ops instead of the CUDA extension.
+"""
+from torch.autograd import Function
+
+from . import graphop as _ops
+
+
+class SparseSoftmax(Function):
+    """y = softmax of edge values per row; apply(row, indptr, eid, x)   (wrapper.py:8-18)"""
+
+    @staticmethod
+    def forward(ctx, row, indptr, eid, x):
+        y = _ops.sparse_softmax_forward(row, indptr, eid, x)
+        ctx.save_for_backward(row, indptr, eid, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        row, indptr, eid, y = ctx.saved_tensors
+        return None, None, None, _ops.sparse_softmax_backward(row, indptr, eid, y, dy)
+
+
+class MaskedMMCSR(Function):
+    """SDDMM; apply(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, A, B)
+    (wrapper.py:20-30)"""
+
+    @staticmethod
+    def forward(ctx, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, A, B):
+        ctx.save_for_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, A, B)
+        return _ops.maskedmm_csr_forward(row, indptr_r, eid_r, indices_r, A, B)
+
+    @staticmethod
+    def backward(ctx, grad):
+        row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, A, B = ctx.saved_tensors
+        dA, dB = _ops.maskedmm_csr_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
+                                            indices_c, A, B, grad)
+        return None, None, None, None, None, None, None, None, dA, dB
+
+
+class NodeMulEdge(Function):
+    """apply(row, indptr, eid, A, B)   (wrapper.py:32-42)"""
+
+    @staticmethod
+    def forward(ctx, row, indptr, eid, A, B):
+        ctx.save_for_backward(row, indptr, eid, A, B)
+        return _ops.node_mul_edge_forward(row, indptr, eid, A, B)
+
+    @staticmethod
+    def backward(ctx, grad):
+        row, indptr, eid, A, B = ctx.saved_tensors
+        dA, dB = _ops.node_mul_edge_backward(row, indptr, eid, A, B, grad)
+        return None, None, None, dA, dB
+
+
+class VectorSPMM(Function):
+    """apply(row, indptr, eid, indices, col, ptr_t, eid_t, indices_t, edata, x)
+    (wrapper.py:44-55)"""
+
+    @staticmethod
+    def forward(ctx, row, indptr, eid, indices, col, ptr_t, eid_t, indices_t, edata, x):
+        y = _ops.vector_spmm_forward(row, indptr, eid, indices, edata, x)
+        ctx.save_for_backward(row, indptr, eid, indices, col, ptr_t, eid_t, indices_t, edata, x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        row, indptr, eid, indices, col, ptr_t, eid_t, indices_t, edata, x = ctx.saved_tensors
+        dedata, dx = _ops.vector_spmm_backward(row, indptr, eid, indices, col, ptr_t, eid_t,
+                                               indices_t, edata, dy.contiguous(), x)
+        return None, None, None, None, None, None, None, None, dedata, dx
+
+
+def attention_step(g, Q, K, V, dO):
+    """One fwd+bwd of the composed hot path the headline metric times:
+    s = SDDMM(Q, K); a = row-softmax(s); o = SpMM(a, V); o.backward(dO).
+    Q, K, V must be leaf tensors with requires_grad; returns (s, a, o)."""
+    args = g.csr_args()
+    s = MaskedMMCSR.apply(*args, Q, K)
+    a = SparseSoftmax.apply(g.row, g.ptr_r, g.eid_r, s)
+    o = VectorSPMM.apply(*args, a, V)
+    o.backward(dO)
+    return s, a, o

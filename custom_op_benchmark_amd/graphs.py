@@ -1,0 +1,145 @@
+"""Graph containers and synthetic graph builders (host-side plumbing, torch tensors).
+
+The reference keeps a graph as eight loose int64 tensors: the row-major chunked CSR
+``(ROW, INDPTR_R, eid_r, indices_r)`` and the column-major one ``(COL, INDPTR_C, eid_c,
+indices_c)`` (``wrapper.py:84-112,198-199``).  ``AttnGraph`` bundles them in the
+positional order the reference's ``Function.apply`` calls use (``wrapper.py:22,46``).
+
+Builders generalise the reference fixture construction (``wrapper.py:93-112``): row-major
+CSR sorted by (src, dst) with ``eid_r = arange(E)``; column-major CSR by a stable sort on
+dst whose ``eid_c`` maps column-order slots back to row-order edge ids.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from .part_csr import partition_csr
+
+
+@dataclass
+class AttnGraph:
+    n_src: int            # rows of the adjacency (query / destination-of-aggregation nodes)
+    n_dst: int            # columns (key / value nodes)
+    n_edges: int
+    src: torch.Tensor     # (E) row id per edge, row-major order
+    dst: torch.Tensor     # (E) col id per edge, row-major order
+    indptr_r: torch.Tensor
+    indptr_c: torch.Tensor
+    row: torch.Tensor     # ROW      chunk -> row id       (partition_csr of indptr_r)
+    ptr_r: torch.Tensor   # INDPTR_R chunk -> first slot
+    eid_r: torch.Tensor
+    indices_r: torch.Tensor
+    col: torch.Tensor     # COL, INDPTR_C, eid_c, indices_c: same for the transposed CSR
+    ptr_c: torch.Tensor
+    eid_c: torch.Tensor
+    indices_c: torch.Tensor
+    chunk_size: int = 32
+
+    def csr_args(self):
+        """The 8 leading positional args of MaskedMMCSR.apply / VectorSPMM.apply."""
+        return (self.row, self.ptr_r, self.eid_r, self.indices_r,
+                self.col, self.ptr_c, self.eid_c, self.indices_c)
+
+    def to(self, device):
+        kw = {}
+        for k, v in self.__dict__.items():
+            kw[k] = v.to(device) if isinstance(v, torch.Tensor) else v
+        return AttnGraph(**kw)
+
+    @property
+    def n_row_chunks(self):
+        return int(self.row.numel())
+
+    @property
+    def n_col_chunks(self):
+        return int(self.col.numel())
+
+
+def graph_from_coo(src, dst, n_src, n_dst=None, chunk_size=32, presorted=False):
+    """Build both chunked CSR orientations from an edge list (duplicates are kept: the
+    kernels treat them as distinct edges)."""
+    n_dst = n_src if n_dst is None else n_dst
+    src = src.to(torch.int64)
+    dst = dst.to(torch.int64)
+    E = int(src.numel())
+    dev = src.device
+    if not presorted and E:
+        key = src * n_dst + dst
+        order = torch.argsort(key, stable=True)
+        src, dst = src[order], dst[order]
+        del key, order
+    indptr_r = torch.zeros(n_src + 1, dtype=torch.int64, device=dev)
+    indptr_c = torch.zeros(n_dst + 1, dtype=torch.int64, device=dev)
+    if E:
+        indptr_r[1:] = torch.cumsum(torch.bincount(src, minlength=n_src), 0)
+        indptr_c[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+    eid_r = torch.arange(E, dtype=torch.int64, device=dev)          # wrapper.py:100
+    indices_r = dst
+    # stable sort by dst keeps src ascending inside a column: same order as wrapper.py:104-112
+    eid_c = torch.argsort(dst, stable=True) if E else eid_r.clone()
+    indices_c = src[eid_c]
+    row, ptr_r = partition_csr(indptr_r, chunk_size)
+    col, ptr_c = partition_csr(indptr_c, chunk_size)
+    return AttnGraph(n_src, n_dst, E, src, dst, indptr_r, indptr_c, row, ptr_r, eid_r, indices_r,
+                     col, ptr_c, eid_c, indices_c, chunk_size)
+
+
+def block_diagonal_graph(batch_size, l, chunk_size=32, device="cpu"):
+    """The reference harness fixture: ``batch_size`` disjoint complete digraphs with
+    self-loops on ``l`` nodes each (``wrapper.py:79-112``).  n = bs*l, e = bs*l*l."""
+    b = torch.arange(batch_size, device=device).view(-1, 1, 1)
+    x = torch.arange(l, device=device).view(1, -1, 1)
+    y = torch.arange(l, device=device).view(1, 1, -1)
+    src = (b * l + x).expand(batch_size, l, l).reshape(-1)
+    dst = (b * l + y).expand(batch_size, l, l).reshape(-1)
+    return graph_from_coo(src, dst, batch_size * l, chunk_size=chunk_size, presorted=True)
+
+
+def uniform_random_graph(n_nodes, n_edges, seed=0, chunk_size=32, device="cpu", n_dst=None):
+    g = torch.Generator(device=device).manual_seed(seed)
+    n_dst = n_nodes if n_dst is None else n_dst
+    src = torch.randint(0, n_nodes, (n_edges,), generator=g, device=device)
+    dst = torch.randint(0, n_dst, (n_edges,), generator=g, device=device)
+    return graph_from_coo(src, dst, n_nodes, n_dst, chunk_size)
+
+
+def powerlaw_weights(n_nodes, alpha, seed, device):
+    """Chung-Lu node weights w_i ~ (rank_i + r0)^-alpha with node ids shuffled, so hubs
+    are not clustered by id.  alpha=0 is uniform."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rank = torch.arange(n_nodes, dtype=torch.float64, device=device)
+    w = (rank + 10.0).pow(-alpha)
+    perm = torch.randperm(n_nodes, generator=g, device=device)
+    out = torch.empty_like(w)
+    out[perm] = w
+    return out / out.sum()
+
+
+def chung_lu_graph(n_nodes, n_edges, alpha=0.5, seed=0, chunk_size=32, device="cpu",
+                   batch=1 << 26):
+    """Reddit-shape stand-in: both endpoints of every edge drawn from one power-law node
+    weight vector (expected degree of node i = E * w_i on both sides), sampled on
+    ``device`` by inverse-CDF search in batches."""
+    w = powerlaw_weights(n_nodes, alpha, seed, device)
+    cdf = torch.cumsum(w, 0)
+    cdf[-1] = 1.0
+    g = torch.Generator(device=device).manual_seed(seed + 1)
+    srcs, dsts = [], []
+    for s in range(0, n_edges, batch):
+        m = min(batch, n_edges - s)
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+        srcs.append(torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1))
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+        dsts.append(torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1))
+    src, dst = torch.cat(srcs), torch.cat(dsts)
+    del srcs, dsts
+    return graph_from_coo(src, dst, n_nodes, n_nodes, chunk_size)
+
+
+SHAPES = {
+    # name: (nodes, edges)  -- shape-matched synthetic stand-ins (no datasets in the image)
+    "cora": (2708, 10556),
+    "reddit": (232965, 114615892),
+    "products": (2449029, 61859140),
+    "harness": (15360, 460800),
+}

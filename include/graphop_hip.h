@@ -1,0 +1,212 @@
+/*
+ * graphop_hip.h -- C ABI of the MI355X (gfx950) graph-attention operator library
+ *                  (libgraphop_hip.so, built from custom_op_benchmark_amd/csrc/).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference exposes the
+ * path as a pybind11 module `graphop` with eight functions on at::Tensor
+ * (graphop/graphop.cpp:216-225).  Each entry point below replaces one of them, with the
+ * tensors flattened to plain device pointers + sizes; a binding (ctypes / pybind / cgo ...)
+ * recovers the reference signature exactly -- see INTEGRATION.md and
+ * custom_op_benchmark_amd/graphop.py (the Python binding shipped here).
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor storage), contiguous,
+ *     row-major; index arrays are int64 exactly as in the reference
+ *     (graphop_kernel.cu:293-296); value arrays are `dtype` (GRAPHOP_F32 / GRAPHOP_F64, the
+ *     reference's AT_DISPATCH_FLOATING_TYPES set, graphop_kernel.cu:291).
+ *   - chunked CSR: row[n_chunks], indptr[n_chunks+1] as produced by partition_csr
+ *     (part_csr.py:13-27); eid[n_edges], indices[n_edges] per CSR slot.
+ *   - node tensors are (n, h, d) -> element (v,k,i) at ((v*h + k)*d + i); edge tensors are
+ *     (n_edges, h).  h == 1 covers the reference's rank-reduced (n, d) / (n_edges) case.
+ *   - outputs are caller-allocated and need NOT be initialised: the callee zero-fills them,
+ *     reproducing the reference's at::zeros outputs (graphop_kernel.cu:284,379-380,429,482,
+ *     527,571-572): slots no chunk covers read 0.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls enqueue work and return
+ *     without synchronising, like the reference (graphop_kernel.cu:288,302).  No global state;
+ *     thread-safe as long as a plan is not destroyed while in use.
+ *   - return value: GRAPHOP_OK or an error code; graphop_last_error() gives the message of the
+ *     calling thread's last failure (the reference throws c10::Error from AT_ASSERTM /
+ *     THCudaCheck instead, graphop.cpp:4-6, graphop_kernel.cu:302).
+ *   - `plan` may be NULL.  A plan (graphop_plan_create) caches per-graph derived structure
+ *     (row segments, flags, 32-bit index mirrors) for one CSR orientation; with it the kernels
+ *     take the row-owned fast paths.  With NULL they take the general path that is correct for
+ *     ANY chunk layout (chunks of a row need not be adjacent), merging chunks of a row with
+ *     float atomics like the reference's dgl::AtomicAdd (graphop/atomic.cuh:57-96).
+ */
+#ifndef GRAPHOP_HIP_H_
+#define GRAPHOP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GRAPHOP_API __attribute__((visibility("default")))
+#else
+#define GRAPHOP_API
+#endif
+
+#define GRAPHOP_ABI_VERSION 1
+
+#define GRAPHOP_F32 0
+#define GRAPHOP_F64 1
+
+#define GRAPHOP_OK 0
+#define GRAPHOP_ERR_INVALID_ARGUMENT 1 /* bad size / dtype / null pointer / plan mismatch   */
+#define GRAPHOP_ERR_HIP 2              /* a HIP runtime call or kernel launch failed        */
+#define GRAPHOP_ERR_BAD_GRAPH 3        /* plan validation: index out of range, bad indptr   */
+
+typedef struct graphop_plan graphop_plan_t; /* opaque */
+
+/* Facts about one chunked-CSR orientation, filled by graphop_plan_create. */
+typedef struct graphop_plan_info {
+  int64_t n_chunks;
+  int64_t n_edges;
+  int64_t n_segments;      /* maximal runs of adjacent chunks with equal row id              */
+  int64_t max_row;         /* largest row id (-1 if no chunks)                               */
+  int64_t max_index;       /* largest value in indices (-1 if none / indices == NULL)        */
+  int64_t max_segment_len; /* slots in the longest segment                                   */
+  int32_t rows_sorted;     /* row[] non-decreasing => a row's chunks are adjacent            */
+  int32_t indptr_monotone; /* indptr[] non-decreasing, within [0, n_edges]                   */
+  int32_t eid_identity;    /* eid[k] == k for all k                                          */
+  int32_t full_coverage;   /* indptr[0] == 0 && indptr[n_chunks] == n_edges                  */
+  int32_t row_owned;       /* rows_sorted && indptr_monotone: fast paths enabled             */
+  int32_t has_idx32;       /* 32-bit mirrors of eid / indices are cached                     */
+} graphop_plan_info_t;
+
+GRAPHOP_API int graphop_abi_version(void);
+GRAPHOP_API const char* graphop_last_error(void);
+
+/* ---- per-kernel timing (measurement aid, off by default) -----------------------------------
+ * When enabled, every hot-path kernel launch is bracketed by two hipEvents recorded on the
+ * launch stream.  graphop_profile_read synchronises them, aggregates per pass tag
+ * ("sddmm_fwd", "softmax_fwd", "spmm_fwd", "spmm_bwd_dedata", "spmm_bwd_dx", "softmax_bwd",
+ * "sddmm_bwd_dA", "sddmm_bwd_dB", ...), clears the log and returns the number of tags. */
+typedef struct graphop_profile_rec {
+  char name[48];
+  int64_t calls;
+  double total_ms;
+  double min_ms;
+  double max_ms;
+} graphop_profile_rec_t;
+GRAPHOP_API int graphop_profile_enable(int on);
+GRAPHOP_API int graphop_profile_read(graphop_profile_rec_t* out, int cap);
+
+/* ---- partition_csr (replaces part_csr.py:13-27 for device-resident indptr) -----------------
+ * count: writes per-row chunk counts' exclusive prefix sum to first_chunk[n_rows+1]
+ *        (first_chunk[n_rows] = C).  The caller reads C back (one 8-byte D2H copy) to size the
+ *        outputs, then calls fill.  scratch: none.
+ * fill:  row[C], indptr_out[C+1]. */
+GRAPHOP_API int graphop_partition_csr_count(const int64_t* indptr, int64_t n_rows, int64_t chunk_size,
+                                int64_t* first_chunk, void* stream);
+GRAPHOP_API int graphop_partition_csr_fill(const int64_t* indptr, const int64_t* first_chunk, int64_t n_rows,
+                               int64_t chunk_size, int64_t n_chunks, int64_t* row,
+                               int64_t* indptr_out, void* stream);
+
+/* ---- plan --------------------------------------------------------------------------------
+ * Analyses (row, indptr, eid, indices) on the device, validates it (indices in [0,n_index_bound),
+ * eid in [0,n_edges), indptr within range) and caches derived arrays.  Synchronises `stream`
+ * once (setup path).  indices may be NULL (softmax / node_mul_edge only need row/indptr/eid).
+ * n_index_bound <= 0 skips the range check of indices.  The arrays must stay alive and
+ * unmodified while the plan is used. */
+GRAPHOP_API int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                        const int64_t* indices, int64_t n_chunks, int64_t n_edges,
+                        int64_t n_index_bound, void* stream, graphop_plan_t** plan_out);
+GRAPHOP_API int graphop_plan_info(const graphop_plan_t* plan, graphop_plan_info_t* info_out);
+GRAPHOP_API void graphop_plan_destroy(graphop_plan_t* plan);
+
+/* ---- SDDMM: maskedmm_csr_forward(row, indptr, eid, indices, A, B) -> y ----------------------
+ * replaces graphop.cpp:16-30 / graphop_kernel.cu:269-304 (kernel :40-55).
+ * y[eid[j], k] = <A[row[c], k, :], B[indices[j], k, :]> for every slot j of every chunk c.
+ * A: (n_a,h,d)  B: (n_b,h,d)  y: (n_edges,h). */
+GRAPHOP_API int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                 const int64_t* eid, const int64_t* indices, const void* A,
+                                 const void* B, void* y, int64_t n_chunks, int64_t n_edges,
+                                 int64_t n_a, int64_t n_b, int64_t h, int64_t d,
+                                 const graphop_plan_t* plan, void* stream);
+
+/* ---- maskedmm_csr_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c,
+ *                            A, B, dy) -> [dA, dB]
+ * replaces graphop.cpp:108-131 / graphop_kernel.cu:355-409 (kernel :100-112, launched twice).
+ * dA[row[c]]  += sum_k dy[eid_r[k]] * B[indices_r[k]]   (row-major CSR)
+ * dB[col[c]]  += sum_k dy[eid_c[k]] * A[indices_c[k]]   (column-major CSR) */
+GRAPHOP_API int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
+                                  const int64_t* eid_r, const int64_t* indices_r,
+                                  const int64_t* col, const int64_t* indptr_c,
+                                  const int64_t* eid_c, const int64_t* indices_c, const void* A,
+                                  const void* B, const void* dy, void* dA, void* dB,
+                                  int64_t n_row_chunks, int64_t n_col_chunks, int64_t n_edges,
+                                  int64_t n_a, int64_t n_b, int64_t h, int64_t d,
+                                  const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
+                                  void* stream);
+
+/* ---- sparse_softmax_forward(row, indptr, eid, x) -> y ---------------------------------------
+ * replaces graphop.cpp:59-69 / graphop_kernel.cu:411-463 (kernels :170-202).
+ * Per (row r, head t): m = max(-1e9, max x), y = exp(x-m) / sum exp(x-m) over all slots of all
+ * chunks with row[c] == r (the -1e9 floor is the reference's max_val fill, :428).
+ * workspace: only used when plan is NULL or not row_owned: 2*workspace_rows*h values of `dtype`,
+ * workspace_rows > max(row[]) (the reference sizes it by n_edges, :420,426-427). */
+GRAPHOP_API int graphop_sparse_softmax_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                   const int64_t* eid, const void* x, void* y, int64_t n_chunks,
+                                   int64_t n_edges, int64_t h, void* workspace,
+                                   int64_t workspace_rows, const graphop_plan_t* plan,
+                                   void* stream);
+
+/* ---- sparse_softmax_backward(row, indptr, eid, y, dy) -> dx ---------------------------------
+ * replaces graphop.cpp:163-175 / graphop_kernel.cu:465-507 (kernels :208-230).
+ * g[r,t] = sum dy*y ; dx = dy*y - g*y.  workspace: workspace_rows*h values (general path). */
+GRAPHOP_API int graphop_sparse_softmax_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                    const int64_t* eid, const void* y, const void* dy, void* dx,
+                                    int64_t n_chunks, int64_t n_edges, int64_t h,
+                                    void* workspace, int64_t workspace_rows,
+                                    const graphop_plan_t* plan, void* stream);
+
+/* ---- vector_spmm_forward(row, indptr, eid, indices, edata, x) -> y --------------------------
+ * replaces graphop.cpp:79-93 / graphop_kernel.cu:509-542 (kernel :118-130).
+ * y[row[c], k, :] += sum_j edata[eid[j], k] * x[indices[j], k, :];  y: (n_y,h,d) where the
+ * reference uses n_y = n_x (zeros_like(x), :527). */
+GRAPHOP_API int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                const int64_t* eid, const int64_t* indices, const void* edata,
+                                const void* x, void* y, int64_t n_chunks, int64_t n_edges,
+                                int64_t n_x, int64_t n_y, int64_t h, int64_t d,
+                                const graphop_plan_t* plan, void* stream);
+
+/* ---- vector_spmm_backward(row, indptr, eid, indices, col, indptr_t, eid_t, indices_t,
+ *                           edata, dy, x) -> [dedata, dx]   (NB: dy before x)
+ * replaces graphop.cpp:190-214 / graphop_kernel.cu:544-600 (kernels :135-163).
+ * dedata[eid[j], k] = <dy[row[c], k, :], x[indices[j], k, :]>           (row-major CSR)
+ * dx[col[c], k, :] += sum_j edata[eid_t[j], k] * dy[indices_t[j], k, :]  (column-major CSR)
+ * Every column chunk is processed (the reference sizes that grid by the ROW chunk count,
+ * graphop_kernel.cu:566,588 -- a latent bug when the counts differ). */
+GRAPHOP_API int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                 const int64_t* eid, const int64_t* indices, const int64_t* col,
+                                 const int64_t* indptr_t, const int64_t* eid_t,
+                                 const int64_t* indices_t, const void* edata, const void* dy,
+                                 const void* x, void* dedata, void* dx, int64_t n_row_chunks,
+                                 int64_t n_col_chunks, int64_t n_edges, int64_t n_x, int64_t n_dy,
+                                 int64_t h, int64_t d, const graphop_plan_t* plan_r,
+                                 const graphop_plan_t* plan_c, void* stream);
+
+/* ---- node_mul_edge_forward(row, indptr, eid, A, B) -> y -------------------------------------
+ * replaces graphop.cpp:39-51 / graphop_kernel.cu:235-266 (kernel :19-34).
+ * y[eid[j], k] = <A[row[c], k, :], B[eid[j], :]>;  B: (n_edges, d) shared by all heads. */
+GRAPHOP_API int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* indptr,
+                                  const int64_t* eid, const void* A, const void* B, void* y,
+                                  int64_t n_chunks, int64_t n_edges, int64_t n_a, int64_t h,
+                                  int64_t d, const graphop_plan_t* plan, void* stream);
+
+/* ---- node_mul_edge_backward(row, indptr, eid, A, B, dy) -> [dA, dB] -------------------------
+ * replaces graphop.cpp:141-154 / graphop_kernel.cu:306-351 (kernels :61-94).
+ * dA[row[c], k, i] += sum_j dy[eid[j], k] * B[eid[j], i];  dB[eid[j], i] = sum_k dy[eid[j],k]*A[row[c],k,i] */
+GRAPHOP_API int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t* indptr,
+                                   const int64_t* eid, const void* A, const void* B,
+                                   const void* dy, void* dA, void* dB, int64_t n_chunks,
+                                   int64_t n_edges, int64_t n_a, int64_t h, int64_t d,
+                                   const graphop_plan_t* plan, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHOP_HIP_H_ */

@@ -1,0 +1,313 @@
+"""GPU tier: the HIP path (through the C ABI, via the Python binding) against the CPU oracle on
+the same seeded inputs, against the committed golden fixtures, and -- at sizes the oracle cannot
+reach -- through size-independent properties.
+
+Tolerances: north_star allows 1e-3 fp32; the tests hold the HIP path to rtol 1e-4 / atol 1e-5
+(fp32, summation order differs from the oracle's serial loops) and 1e-10 / 1e-12 (fp64).
+Index outputs (partition_csr) are compared bit-exact in test_partition_csr.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from custom_op_benchmark_amd import _lib, functions, graphs
+from custom_op_benchmark_amd import graphop as ops
+
+from util import oracle_step, rand_inputs, random_graph, t
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(rtol=1e-4, atol=1e-5), torch.float64: dict(rtol=1e-10, atol=1e-12)}
+
+
+def close(got, want, dtype=torch.float32, **kw):
+    tol = dict(TOL[dtype]); tol.update(kw)
+    torch.testing.assert_close(got.cpu(), want, **tol)
+
+
+def hip_step(g, Q, K, V, dO):
+    """Composed step through the product's autograd classes on the GPU."""
+    Q = Q.clone().requires_grad_(True); K = K.clone().requires_grad_(True); V = V.clone().requires_grad_(True)
+    a8 = g.csr_args()
+    s = functions.MaskedMMCSR.apply(*a8, Q, K)
+    a = functions.SparseSoftmax.apply(g.row, g.ptr_r, g.eid_r, s)
+    o = functions.VectorSPMM.apply(*a8, a, V)
+    o.backward(dO)
+    torch.cuda.synchronize()
+    return dict(s=s.detach(), a=a.detach(), o=o.detach(), dQ=Q.grad, dK=K.grad, dV=V.grad)
+
+
+# ---- golden fixtures -----------------------------------------------------------------------------
+@pytest.mark.parametrize("cs", [3, 32])
+@pytest.mark.parametrize("h", [1, 8])
+def test_k2_harness_fixture_on_gpu(golden, dev, cs, h):
+    z = golden("k2_harness_small.npz")
+    a8 = tuple(t(z["cs%d_%s" % (cs, k)], dev) for k in ("row", "ptr_r", "eid_r", "indices_r", "col",
+                                                        "ptr_c", "eid_c", "indices_c"))
+    p = "h%d_" % h
+    A, B, ge, gn, x, w = (t(z[p + k], dev) for k in ("A", "B", "grad_e", "grad_n", "x", "w"))
+    close(ops.maskedmm_csr_forward(*a8[:4], A, B), t(z[p + "sddmm_y"]))
+    dA, dB = ops.maskedmm_csr_backward(*a8, A, B, ge)
+    close(dA, t(z[p + "sddmm_dA"])); close(dB, t(z[p + "sddmm_dB"]))
+    y = ops.sparse_softmax_forward(*a8[:3], x)
+    close(y, t(z[p + "sm_scatter_y"]))
+    close(ops.sparse_softmax_backward(*a8[:3], y, ge), t(z[p + "sm_scatter_dx"]), rtol=1e-3, atol=1e-6)
+    y = ops.sparse_softmax_forward(*a8[4:7], x)
+    close(y, t(z[p + "sm_gather_y"]))
+    close(ops.sparse_softmax_backward(*a8[4:7], y, ge), t(z[p + "sm_gather_dx"]), rtol=1e-3, atol=1e-6)
+    close(ops.vector_spmm_forward(*a8[:4], w, A), t(z[p + "spmm_y"]))
+    dw, dx = ops.vector_spmm_backward(*a8, w, gn, A)
+    close(dw, t(z[p + "spmm_dw"])); close(dx, t(z[p + "spmm_dx"]))
+
+
+def test_k3_maskedmm_simple_on_gpu(golden, dev):
+    z = golden("k3_maskedmm_simple.npz")
+    a8 = tuple(t(z[k], dev) for k in ("row", "ptr_r", "eid_r", "indices_r", "col", "ptr_c", "eid_c", "indices_c"))
+    A = t(z["A"], dev).requires_grad_(True); B = t(z["B"], dev).requires_grad_(True)
+    y = functions.MaskedMMCSR.apply(*a8, A, B)
+    y.backward(t(z["grad"], dev))
+    close(y.detach(), t(z["y"])); close(A.grad, t(z["dA"])); close(B.grad, t(z["dB"]))
+
+
+@pytest.mark.parametrize("h", [1, 2])
+def test_k4_function_classes_on_gpu(golden, dev, h):
+    """Our autograd classes reproduce what the reference's classes returned (arg order, return
+    order, grad routing -- wrapper.py:8-55)."""
+    z = golden("k4_function_classes.npz")
+    a8 = tuple(t(z[k], dev) for k in ("row", "ptr_r", "eid_r", "indices_r", "col", "ptr_c", "eid_c", "indices_c"))
+    p = "h%d_" % h
+    A, B, x, w, Be = (t(z[p + k], dev).requires_grad_(True) for k in ("A", "B", "x", "w", "Be"))
+    ge, gn = t(z[p + "ge"], dev), t(z[p + "gn"], dev)
+    y = functions.MaskedMMCSR.apply(*a8, A, B); y.backward(ge)
+    close(y.detach(), t(z[p + "mm_y"])); close(A.grad, t(z[p + "mm_dA"])); close(B.grad, t(z[p + "mm_dB"]))
+    A.grad = None
+    y = functions.SparseSoftmax.apply(*a8[:3], x); y.backward(ge)
+    close(y.detach(), t(z[p + "sm_y"])); close(x.grad, t(z[p + "sm_dx"]))
+    x.grad = None
+    y = functions.SparseSoftmax.apply(*a8[4:7], x); y.backward(ge)
+    close(y.detach(), t(z[p + "smg_y"])); close(x.grad, t(z[p + "smg_dx"]))
+    y = functions.VectorSPMM.apply(*a8, w, A); y.backward(gn)
+    close(y.detach(), t(z[p + "sp_y"])); close(w.grad, t(z[p + "sp_dw"])); close(A.grad, t(z[p + "sp_dx"]))
+    A.grad = None
+    y = functions.NodeMulEdge.apply(*a8[:3], A, Be); y.backward(ge)
+    close(y.detach(), t(z[p + "ne_y"])); close(A.grad, t(z[p + "ne_dA"])); close(Be.grad, t(z[p + "ne_dB"]))
+
+
+# ---- HIP vs oracle on irregular graphs -----------------------------------------------------------
+CONFIGS = [(1, 64), (1, 16), (1, 32), (1, 128), (1, 256), (1, 512), (1, 1024),   # fast h = 1
+           (8, 64), (8, 16), (2, 32), (4, 4), (8, 128), (16, 8),                 # fast multi-head
+           (1, 7), (3, 5), (2, 6), (1, 20), (1, 2048)]                           # generic
+
+
+@pytest.mark.parametrize("h,d", CONFIGS)
+def test_step_vs_oracle_irregular(dev, h, d):
+    n = 90 if h * d >= 512 else 300
+    g = random_graph(n, n + 37, 12 * n, seed=h * 1000 + d, chunk_size=32, zero_rows=0.15, hub=700)
+    inp = rand_inputs(g, h, d, seed=3, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    got = hip_step(gd, *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
+
+
+@pytest.mark.parametrize("h,d", [(1, 64), (4, 16), (3, 5)])
+def test_step_vs_oracle_fp64(dev, h, d):
+    g = random_graph(120, 150, 2000, seed=d, chunk_size=8, zero_rows=0.1, hub=300)
+    inp = rand_inputs(g, h, d, seed=4, dtype=torch.float64, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k], torch.float64)
+
+
+@pytest.mark.parametrize("chunk_size", [1, 5, 32, 1000])
+def test_chunk_sizes(dev, chunk_size):
+    g = random_graph(200, 200, 6000, seed=chunk_size, chunk_size=chunk_size, zero_rows=0.1, hub=400)
+    inp = rand_inputs(g, 1, 64, seed=5)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
+
+
+@pytest.mark.parametrize("h,d", [(1, 64), (8, 16), (3, 5)])
+def test_unordered_chunks_take_the_general_path(dev, h, d):
+    """Chunks of a row need not be adjacent: shuffle the chunk list (row[] unsorted).  The plan
+    reports row_owned = 0 and every op falls back to the atomics path; results still match."""
+    g = random_graph(150, 150, 5000, seed=11, chunk_size=8, hub=300)
+    inp = rand_inputs(g, h, d, seed=6, normal=True)
+    gen = torch.Generator().manual_seed(0)
+
+    def shuffled(row, ptr):
+        C = row.numel()
+        perm = torch.randperm(C, generator=gen)
+        # a chunked CSR needs contiguous [ptr[c], ptr[c+1]) slots, so reorder the slots too
+        lens = (ptr[1:] - ptr[:-1])[perm]
+        new_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+        slot = torch.cat([torch.arange(int(ptr[c]), int(ptr[c + 1])) for c in perm.tolist()])
+        return row[perm].contiguous(), new_ptr, slot
+
+    row, ptr_r, sr = shuffled(g.row, g.ptr_r)
+    col, ptr_c, sc = shuffled(g.col, g.ptr_c)
+    a8 = (row, ptr_r, g.eid_r[sr].contiguous(), g.indices_r[sr].contiguous(),
+          col, ptr_c, g.eid_c[sc].contiguous(), g.indices_c[sc].contiguous())
+    Q, K, V, dO, x, ge = (inp[k] for k in ("Q", "K", "V", "dO", "x", "ge"))
+    a8d = tuple(v.to(dev) for v in a8)
+    plan = _lib.get_plan(*a8d[:4], n_index_bound=g.n_dst)
+    assert plan.info.row_owned == 0 and plan.info.rows_sorted == 0
+    close(ops.maskedmm_csr_forward(*a8d[:4], Q.to(dev), K.to(dev)), oracle.maskedmm_csr_forward(*a8[:4], Q, K))
+    y = ops.sparse_softmax_forward(*a8d[:3], x.to(dev))
+    yo = oracle.sparse_softmax_forward(*a8[:3], x)
+    close(y, yo)
+    close(ops.sparse_softmax_backward(*a8d[:3], y, ge.to(dev)), oracle.sparse_softmax_backward(*a8[:3], yo, ge))
+    close(ops.vector_spmm_forward(*a8d[:4], x.to(dev), V.to(dev)), oracle.vector_spmm_forward(*a8[:4], x, V))
+    dw, dx = ops.vector_spmm_backward(*a8d, x.to(dev), dO.to(dev), V.to(dev))
+    dwo, dxo = oracle.vector_spmm_backward(*a8, x, dO, V)
+    close(dw, dwo); close(dx, dxo)
+    dA, dB = ops.maskedmm_csr_backward(*a8d, Q.to(dev), K.to(dev), ge.to(dev))
+    dAo, dBo = oracle.maskedmm_csr_backward(*a8, Q, K, ge)
+    close(dA, dAo); close(dB, dBo)
+
+
+def test_partial_coverage_leaves_zeros(dev):
+    """Slots no chunk covers read 0 (outputs are at::zeros in the reference, :284,429)."""
+    g = graphs.uniform_random_graph(50, 800, seed=9, chunk_size=4)
+    inp = rand_inputs(g, 1, 64, seed=1)
+    C = g.row.numel() // 2
+    row, ptr = g.row[:C].contiguous(), g.ptr_r[: C + 1].contiguous()
+    yo = oracle.maskedmm_csr_forward(row, ptr, g.eid_r, g.indices_r, inp["Q"], inp["K"])
+    y = ops.maskedmm_csr_forward(row.to(dev), ptr.to(dev), g.eid_r.to(dev), g.indices_r.to(dev),
+                                 inp["Q"].to(dev), inp["K"].to(dev))
+    close(y, yo)
+    assert (y[int(ptr[-1]):] == 0).all()
+    so = oracle.sparse_softmax_forward(row, ptr, g.eid_r, inp["x"])
+    s = ops.sparse_softmax_forward(row.to(dev), ptr.to(dev), g.eid_r.to(dev), inp["x"].to(dev))
+    close(s, so)
+    assert (s[int(ptr[-1]):] == 0).all()
+
+
+def test_empty_graphs(dev):
+    z = torch.zeros(0, dtype=torch.int64, device=dev)
+    ptr = torch.zeros(1, dtype=torch.int64, device=dev)
+    A = torch.rand(5, 64, device=dev)
+    y = ops.maskedmm_csr_forward(z, ptr, z, z, A, A)
+    assert y.shape == (0,)
+    dA, dB = ops.maskedmm_csr_backward(z, ptr, z, z, z, ptr, z, z, A, A, y)
+    assert (dA == 0).all() and (dB == 0).all() and dA.shape == A.shape
+    assert ops.sparse_softmax_forward(z, ptr, z, y).shape == (0,)
+    o = ops.vector_spmm_forward(z, ptr, z, z, y, A)
+    assert (o == 0).all() and o.shape == A.shape
+    dw, dx = ops.vector_spmm_backward(z, ptr, z, z, z, ptr, z, z, y, A, A)
+    assert dw.shape == (0,) and (dx == 0).all()
+
+
+def test_softmax_floor_and_large_values(dev):
+    g = graphs.graph_from_coo(torch.tensor([0, 0, 1, 1]), torch.tensor([0, 1, 1, 0]), 2).to(dev)
+    x = torch.tensor([-2e9, -3e9, 80.0, -80.0], device=dev)
+    y = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, x)
+    yo = oracle.sparse_softmax_forward(g.row.cpu(), g.ptr_r.cpu(), g.eid_r.cpu(), x.cpu())
+    assert torch.isnan(y[:2]).all() and torch.isnan(yo[:2]).all()      # -1e9 floor, :428
+    close(y[2:], yo[2:])
+    x64 = torch.tensor([700.0, 699.0, -5.0, 3.0], device=dev, dtype=torch.float64)
+    close(ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, x64),
+          oracle.sparse_softmax_forward(g.row.cpu(), g.ptr_r.cpu(), g.eid_r.cpu(), x64.cpu()), torch.float64)
+
+
+def test_error_behaviour_on_gpu(dev):
+    g = graphs.uniform_random_graph(20, 100, seed=2).to(dev)
+    A = torch.rand(20, 64, device=dev)
+    with pytest.raises(RuntimeError, match="A must be contiguous"):            # graphop.cpp:5
+        ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, A.t().contiguous().t(), A)
+    with pytest.raises(RuntimeError, match="Long"):
+        ops.maskedmm_csr_forward(g.row.int(), g.ptr_r, g.eid_r, g.indices_r, A, A)
+    with pytest.raises(RuntimeError, match="float32 / float64"):
+        ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, A.half(), A.half())
+    bad = g.indices_r.clone(); bad[3] = 20                                       # out of range
+    with pytest.raises(RuntimeError, match="indices value"):
+        ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, bad, A, A)
+    with pytest.raises(RuntimeError, match="only"):
+        ops.vector_spmm_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, torch.rand(100, device=dev), A[:10].contiguous())
+
+
+def test_torch_ops_namespace_on_gpu(dev):
+    g = graphs.uniform_random_graph(64, 2000, seed=3).to(dev)
+    A = torch.rand(64, 64, device=dev); B = torch.rand(64, 64, device=dev)
+    y1 = torch.ops.graphop.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, A, B)
+    y2 = ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, A, B)
+    assert torch.equal(y1, y2)
+    out = torch.ops.graphop.vector_spmm_backward(*g.csr_args(), y1, A, B)
+    assert isinstance(out, (list, tuple)) and len(out) == 2
+
+
+def test_node_mul_edge_vs_oracle(dev):
+    for h, d in ((1, 64), (8, 64), (2, 5)):
+        g = random_graph(100, 100, 3000, seed=h + d, chunk_size=32, zero_rows=0.1, hub=200)
+        gen = torch.Generator().manual_seed(1)
+        A = torch.rand((100, d) if h == 1 else (100, h, d), generator=gen)
+        Be = torch.rand(g.n_edges, d, generator=gen)
+        ge = torch.rand((g.n_edges,) if h == 1 else (g.n_edges, h), generator=gen)
+        a3 = (g.row, g.ptr_r, g.eid_r)
+        a3d = tuple(v.to(dev) for v in a3)
+        close(ops.node_mul_edge_forward(*a3d, A.to(dev), Be.to(dev)), oracle.node_mul_edge_forward(*a3, A, Be))
+        dA, dB = ops.node_mul_edge_backward(*a3d, A.to(dev), Be.to(dev), ge.to(dev))
+        dAo, dBo = oracle.node_mul_edge_backward(*a3, A, Be, ge)
+        close(dA, dAo); close(dB, dBo)
+
+
+# ---- medium size vs oracle, and full-size properties ----------------------------------------------
+def test_medium_powerlaw_vs_oracle(dev):
+    """~1M edges, power-law degrees (hubs of thousands of edges), d = 64: the oracle takes seconds."""
+    g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=0)
+    inp = rand_inputs(g, 1, 64, seed=7, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k], rtol=2e-4, atol=2e-5)
+
+
+def test_reddit_scale_properties(dev):
+    """BASELINE config 2 size (N = 232,965, E = 114,615,892, d = 64): size-independent checks.
+      * softmax rows sum to 1 and y > 0; backward of a constant upstream gradient is ~0
+      * SDDMM of all-ones operands = d on every edge; SpMM with unit weights of all-ones = degree
+      * linearity of SDDMM in A; a second run is bit-identical for the atomic-free ops
+      * adjointness: <SpMM(w, X), G> = <w, dedata> = <X, dx> ties forward and both backward passes
+    """
+    N, E = graphs.SHAPES["reddit"]
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev)
+    d = 64
+    gen = torch.Generator(device=dev).manual_seed(1)
+    Q = torch.rand(N, d, device=dev, generator=gen); K = torch.rand(N, d, device=dev, generator=gen)
+    a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+    ones = torch.ones(N, d, device=dev)
+    s1 = ops.maskedmm_csr_forward(*a4, ones, ones)
+    assert torch.equal(s1, torch.full_like(s1, float(d)))
+    deg = (g.indptr_r[1:] - g.indptr_r[:-1]).float()
+    o1 = ops.vector_spmm_forward(*a4, torch.ones(E, device=dev), ones)
+    torch.testing.assert_close(o1[:, 0], deg, rtol=1e-5, atol=0)
+    del s1, o1, ones
+    s = ops.maskedmm_csr_forward(*a4, Q, K)
+    assert torch.equal(s, ops.maskedmm_csr_forward(*a4, Q, K))               # deterministic
+    s2 = ops.maskedmm_csr_forward(*a4, 2 * Q, K)
+    torch.testing.assert_close(s2, 2 * s, rtol=1e-6, atol=0)                  # linear in A
+    del s2
+    a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+    assert torch.equal(a, ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s))
+    assert float(a.min()) > 0
+    rowsum = torch.zeros(N, device=dev, dtype=torch.float64).index_add_(0, g.src, a.double())
+    nz = deg > 0
+    torch.testing.assert_close(rowsum[nz], torch.ones_like(rowsum[nz]), rtol=0, atol=1e-5)
+    dsm = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, torch.full_like(a, 3.0))
+    assert float(dsm.abs().max()) < 1e-4
+    del dsm, rowsum
+    V = torch.rand(N, d, device=dev, generator=gen); G = torch.rand(N, d, device=dev, generator=gen)
+    o = ops.vector_spmm_forward(*a4, a, V)
+    da, dV = ops.vector_spmm_backward(*g.csr_args(), a, G, V)
+    lhs = (o.double() * G.double()).sum()
+    torch.testing.assert_close((a.double() * da.double()).sum(), lhs, rtol=1e-6, atol=0)
+    torch.testing.assert_close((V.double() * dV.double()).sum(), lhs, rtol=1e-6, atol=0)
+    dQ, dK = ops.maskedmm_csr_backward(*g.csr_args(), Q, K, da)
+    ref = (s.double() * da.double()).sum()          # <SDDMM(Q,K), da> = <Q, dQ> = <K, dK>
+    torch.testing.assert_close((Q.double() * dQ.double()).sum(), ref, rtol=1e-6, atol=0)
+    torch.testing.assert_close((K.double() * dK.double()).sum(), ref, rtol=1e-6, atol=0)
