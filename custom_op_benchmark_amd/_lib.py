@@ -37,6 +37,7 @@ class ProfileRec(ctypes.Structure):
 # name -> argtypes (all return int unless noted); mirrors include/graphop_hip.h one to one
 _P = _vp
 _SIGNATURES = {
+    "graphop_tune": [ctypes.c_char_p, ctypes.c_int],
     "graphop_profile_enable": [ctypes.c_int],
     "graphop_profile_read": [ctypes.POINTER(ProfileRec), ctypes.c_int],
     "graphop_partition_csr_count": [_P, _c64, _c64, _P, _P],
@@ -161,6 +162,11 @@ def get_plan(row, indptr, eid, indices=None, n_index_bound=0):
         raise RuntimeError("graphop: indices holds %d but the gathered tensor has only %d rows"
                            % (p.info.max_index, n_index_bound))
     return p
+
+
+def tune(key, value):
+    """Set a tuning knob (include/graphop_hip.h: graphop_tune)."""
+    check(lib().graphop_tune(key.encode(), int(value)))
 
 
 def profile_enable(on=True):

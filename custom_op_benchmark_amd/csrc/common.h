@@ -55,12 +55,28 @@ struct PlanStats {  // device-resident while the analysis kernels run, then copi
   i64 max_index;
   i64 max_seg_len;
   i64 n_segments;
+  i64 unsorted_ids;      // #adjacent slot pairs of one row with indices[k] > indices[k+1]
 };
 
 }  // namespace graphop
 
+namespace graphop {
+// Window-sweep structure of one plan for a given window geometry (see kernels_fast.h).
+struct Sweep {
+  int W = 0;            // number of column windows
+  i64 win_cols = 0;     // ids per window
+  int T = 0;            // longest vrow (rows longer than T slots are cut into pieces)
+  int V = 0;            // number of vrows
+  int* vr_row = nullptr;  // [V] owning row id
+  int* wp = nullptr;      // [(W+1)*V] window boundaries (slot indices)
+};
+}  // namespace graphop
+
 struct graphop_plan {
   graphop_plan_info_t info;
+  int sorted_in_rows;      // neighbour ids ascend inside every row segment
+  void* sweeps;            // std::vector<graphop::Sweep>* (lazily built, guarded by sweep_mu)
+  void* sweep_mu;          // std::mutex*
   const int64_t* row;      // identity of the arrays the plan was built from (not owned)
   const int64_t* indptr;
   const int64_t* eid;

@@ -50,6 +50,9 @@ struct ProfScope {  // brackets one kernel launch with two events when profiling
 int partition_count(const i64*, i64, i64, i64*, hipStream_t);
 int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_t);
 int plan_build(graphop_plan*, i64, hipStream_t);
+int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
+void plan_init_sweeps(graphop_plan*);
+void plan_free_sweeps(graphop_plan*);
 
 namespace {
 
@@ -57,7 +60,28 @@ struct Tuning {
   int sddmm_cpg;  // chunks per lane-group, SDDMM-type kernels
   int spmm_cpg;   // chunks per lane-group, SpMM-type kernels
   int force_generic;
+  int sweep;            // use the window-sweep drivers when a plan allows it
+  int window_kb;        // target bytes of gathered table per window (must sit in a 4 MiB L2)
+  int max_windows;
+  int sweep_min_kb;     // tables smaller than this are L2-friendly enough for the chunk drivers
+  int sweep_bpc;        // resident blocks per CU for the sweep drivers
+  int sweep_k;          // vrows per lane group (0 = auto)
+  int vrow_t;           // vrow length cap (0 = auto from the mean row length)
+  int n_cu;
   Tuning() {
+    sweep = env_int("GRAPHOP_SWEEP", 1);
+    window_kb = env_int("GRAPHOP_WINDOW_KB", 2048);
+    max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
+    sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 6144);
+    sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
+    sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
+    vrow_t = env_int("GRAPHOP_VROW_T", 0);
+    n_cu = 256;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
     sddmm_cpg = env_int("GRAPHOP_SDDMM_CPG", 8);
     spmm_cpg = env_int("GRAPHOP_SPMM_CPG", 16);
     force_generic = env_int("GRAPHOP_FORCE_GENERIC", 0);
@@ -65,10 +89,11 @@ struct Tuning {
     if (spmm_cpg < 1) spmm_cpg = 1;
   }
 };
-const Tuning& tuning() {
+Tuning& tuning_mut() {
   static Tuning t;
   return t;
 }
+const Tuning& tuning() { return tuning_mut(); }
 
 inline size_t esize(int dtype) { return dtype == GRAPHOP_F64 ? 8 : 4; }
 
@@ -100,17 +125,132 @@ inline bool fast_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_src_rows) {
     default: break;                                                  \
   }
 
+inline bool plan_matches_full(const graphop_plan* p, const i64* row, const i64* indptr,
+                              const i64* eid, const i64* indices, i64 C, i64 E) {
+  return p && p->row == (const int64_t*)row && p->indptr == (const int64_t*)indptr &&
+         p->eid == (const int64_t*)eid && p->indices == (const int64_t*)indices &&
+         p->info.n_chunks == C && p->info.n_edges == E;
+}
+
+inline i64 pow2ceil(i64 v) { i64 p = 1; while (p < v) p <<= 1; return p; }
+
+struct SweepLaunch {
+  SweepView view;
+  unsigned blocks;
+  size_t lds_bytes;
+};
+
+// Decide whether the window-sweep driver applies and fetch / build its structure.
+// Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
+inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
+                        SweepLaunch* out) {
+  const Tuning& t = tuning();
+  if (!t.sweep || !plan) return 0;
+  const graphop_plan_info_t& pi = plan->info;
+  if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
+  if (!pi.eid_identity && !plan->eid32) return 0;
+  if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
+  const i64 row_bytes = 16LL * L * NV;
+  const i64 table_bytes = n_table_rows * row_bytes;
+  if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
+  i64 W = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
+  if (W > t.max_windows) W = t.max_windows;
+  if (W < 2) return 0;
+  const i64 win_cols = ceil_div(n_table_rows, W);
+  int T = t.vrow_t;
+  if (T <= 0) {
+    const i64 mean = pi.n_edges / pi.n_segments;
+    T = (int)pow2ceil(mean > 0 ? mean : 1);
+    if (T < 64) T = 64;
+    if (T > 4096) T = 4096;
+  }
+  const Sweep* sw = nullptr;
+  const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
+  if (rc != GRAPHOP_OK) return -rc;
+  int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
+  if (K > L) K = L;
+  const int gpb = kFastBlock / L;
+  i64 blocks = (i64)t.n_cu * t.sweep_bpc;
+  i64 rounds = ceil_div(sw->V, blocks * gpb * K);
+  if (rounds <= 1) {
+    rounds = 1;
+    blocks = ceil_div(ceil_div(sw->V, K), gpb);
+  }
+  out->view.wp = sw->wp;
+  out->view.vr_row = sw->vr_row;
+  out->view.idx32 = plan->idx32;
+  out->view.eid32 = plan->eid32;
+  out->view.V = sw->V;
+  out->view.W = sw->W;
+  out->view.K = K;
+  out->view.rounds = (int)rounds;
+  out->blocks = (unsigned)blocks;
+  out->lds_bytes = (size_t)gpb * K * row_bytes;
+  return 1;
+}
+
+template <int L, int NV>
+int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
+                    const void* B, void* y, i64 h, int d4, hipStream_t st) {
+  SweepLaunch sl;
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
+  if (use != 1) return use;
+  ProfScope prof(tag, st);
+  const bool id = plan->info.eid_identity != 0;
+  const dim3 grid(sl.blocks), block(kFastBlock);
+  const float* a = (const float*)A;
+  const float* b = (const float*)B;
+  float* yy = (float*)y;
+  if (h == 1) {
+    if (id) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, true, true>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+    else hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, true, false>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+  } else {
+    if (id) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, false, true>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+    else hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, false, false>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+  }
+  return 1;
+}
+
+template <int L, int NV>
+int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w,
+                   const void* X, void* out, i64 h, int d4, hipStream_t st) {
+  SweepLaunch sl;
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
+  if (use != 1) return use;
+  ProfScope prof(tag, st);
+  const bool id = plan->info.eid_identity != 0;
+  const dim3 grid(sl.blocks), block(kFastBlock);
+  const float* ww = (const float*)w;
+  const float* x = (const float*)X;
+  float* o = (float*)out;
+  if (h == 1) {
+    if (id) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, true, true>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+    else hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, true, false>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+  } else {
+    if (id) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, false, true>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+    else hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, false, false>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+  }
+  return 1;
+}
+
 // ---- launch helpers -------------------------------------------------------------------------------
 template <bool EDGE_B>
 int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
                  const i64* indices, const void* A, const void* B, void* y, i64 C, i64 E,
-                 i64 n_src_rows, i64 h, i64 d, hipStream_t st) {
+                 i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
   if (C == 0) return GRAPHOP_OK;
-  ProfScope prof(tag, st);
+  if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   // EDGE_B (node_mul_edge): B rows are d wide, A rows h*d wide -> fast path only for h == 1
   if (fast_ok(dtype, h, d, E, n_src_rows) && (!EDGE_B || h == 1)) {
     const int cpg = tuning().sddmm_cpg;
     const int F = (int)(h * d), d4 = (int)(d / 4);
+    if constexpr (!EDGE_B) {
+      int use = 0;
+      GO_DISPATCH_LNV(F, { use = try_sddmm_sweep<L, NV>(tag, plan, n_src_rows, A, B, y, h, d4, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+    }
+    ProfScope prof(tag, st);
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
@@ -124,6 +264,7 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
                            C, (int)h, d4, cpg);
     });
   } else {
+    ProfScope prof(tag, st);
     const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
     if (dtype == GRAPHOP_F32)
       hipLaunchKernelGGL((k_sddmm_generic<float, EDGE_B>), dim3(nb), dim3(kGenericBlock), 0, st,
@@ -141,12 +282,19 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
 template <bool EDGE_X>
 int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
                 const i64* indices, const void* w, const void* X, void* out, i64 C, i64 E,
-                i64 n_src_rows, i64 h, i64 d, hipStream_t st) {
+                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
   if (C == 0) return GRAPHOP_OK;
-  ProfScope prof(tag, st);
+  if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
     const int cpg = tuning().spmm_cpg;
     const int F = (int)(h * d), d4 = (int)(d / 4);
+    {
+      int use = 0;
+      GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+    }
+    ProfScope prof(tag, st);
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
@@ -160,6 +308,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
                            (int)h, d4, cpg);
     });
   } else {
+    ProfScope prof(tag, st);
     const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
     if (dtype == GRAPHOP_F32)
       hipLaunchKernelGGL((k_spmm_generic<float, EDGE_X>), dim3(nb), dim3(kGenericBlock), 0, st,
@@ -296,6 +445,23 @@ extern "C" {
 int graphop_abi_version(void) { return GRAPHOP_ABI_VERSION; }
 const char* graphop_last_error(void) { return get_error(); }
 
+int graphop_tune(const char* key, int value) {
+  GO_CHECK_ARG(key != nullptr, "tune: key is NULL");
+  Tuning& t = tuning_mut();
+  struct { const char* k; int* p; } tab[] = {
+      {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
+      {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"max_windows", &t.max_windows},
+      {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
+      {"vrow_t", &t.vrow_t}};
+  for (auto& e : tab)
+    if (strcmp(e.k, key) == 0) {
+      *e.p = value;
+      return GRAPHOP_OK;
+    }
+  set_error("tune: unknown key '%s'", key);
+  return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
 int graphop_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
@@ -373,6 +539,7 @@ int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t
   p->info.n_chunks = n_chunks;
   p->info.n_edges = n_edges;
   (void)hipGetDevice(&p->device);
+  plan_init_sweeps(p);
   const int rc = plan_build(p, n_index_bound, (hipStream_t)stream);
   if (rc != GRAPHOP_OK) {
     graphop_plan_destroy(p);
@@ -390,6 +557,7 @@ int graphop_plan_info(const graphop_plan_t* plan, graphop_plan_info_t* info_out)
 
 void graphop_plan_destroy(graphop_plan_t* plan) {
   if (!plan) return;
+  plan_free_sweeps(plan);
   if (plan->seg_chunk) (void)hipFree(plan->seg_chunk);
   if (plan->idx32) (void)hipFree(plan->idx32);
   if (plan->eid32) (void)hipFree(plan->eid32);
@@ -415,7 +583,7 @@ int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* i
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, A); GO_PTR(fn, B);
   (void)n_a;
   return launch_sddmm<false>("sddmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                             (const i64*)indices, A, B, y, n_chunks, n_edges, n_b, h, d, st);
+                             (const i64*)indices, A, B, y, n_chunks, n_edges, n_b, h, d, plan, st);
 }
 
 int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
@@ -431,7 +599,6 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   GO_TRY(check_common(fn, dtype, n_row_chunks, n_edges, h, d));
   GO_CHECK_ARG(n_col_chunks >= 0 && n_a >= 0 && n_b >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
-  (void)plan_r; (void)plan_c;
   const size_t es = esize(dtype);
   if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
   if (n_b * h * d > 0) { GO_PTR(fn, dB); GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_b * h * d), st)); }
@@ -439,12 +606,12 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   if (n_row_chunks > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr_r); GO_PTR(fn, eid_r); GO_PTR(fn, indices_r); GO_PTR(fn, B); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dA", dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r,
-                              (const i64*)indices_r, dy, B, dA, n_row_chunks, n_edges, n_b, h, d, st));
+                              (const i64*)indices_r, dy, B, dA, n_row_chunks, n_edges, n_b, h, d, plan_r, st));
   }
   if (n_col_chunks > 0) {
     GO_PTR(fn, col); GO_PTR(fn, indptr_c); GO_PTR(fn, eid_c); GO_PTR(fn, indices_c); GO_PTR(fn, A); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dB", dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
-                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, st));
+                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st));
   }
   return GRAPHOP_OK;
 }
@@ -498,14 +665,13 @@ int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* in
   GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
   GO_CHECK_ARG(n_x >= 0 && n_y >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
-  (void)plan;
   if (n_y * h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
   GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_y * h * d), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, edata); GO_PTR(fn, x);
   return launch_spmm<false>("spmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                            (const i64*)indices, edata, x, y, n_chunks, n_edges, n_x, h, d, st);
+                            (const i64*)indices, edata, x, y, n_chunks, n_edges, n_x, h, d, plan, st);
 }
 
 int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* indptr,
@@ -520,7 +686,6 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
   GO_TRY(check_common(fn, dtype, n_row_chunks, n_edges, h, d));
   GO_CHECK_ARG(n_col_chunks >= 0 && n_x >= 0 && n_dy >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
-  (void)plan_c;
   const size_t es = esize(dtype);
   if (n_edges * h > 0) {
     GO_PTR(fn, dedata);
@@ -536,13 +701,13 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, dy); GO_PTR(fn, x);
     // kernel_0: dedata = SDDMM(dy, x) over the row-major CSR (graphop_kernel.cu:135-149)
     GO_TRY(launch_sddmm<false>("spmm_bwd_dedata", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                               (const i64*)indices, dy, x, dedata, n_row_chunks, n_edges, n_x, h, d, st));
+                               (const i64*)indices, dy, x, dedata, n_row_chunks, n_edges, n_x, h, d, plan_r, st));
   }
   if (n_col_chunks > 0) {
     GO_PTR(fn, col); GO_PTR(fn, indptr_t); GO_PTR(fn, eid_t); GO_PTR(fn, indices_t); GO_PTR(fn, edata); GO_PTR(fn, dy);
     // kernel_1: dx = SpMM(edata, dy) over the column-major CSR, all C' chunks (:151-163)
     GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
-                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, st));
+                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st));
   }
   return GRAPHOP_OK;
 }
@@ -561,7 +726,7 @@ int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* 
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B);
   return launch_sddmm<true>("node_mul_edge_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                            (const i64*)eid, A, B, y, n_chunks, n_edges, n_edges, h, d, st);
+                            (const i64*)eid, A, B, y, n_chunks, n_edges, n_edges, h, d, nullptr, st);
 }
 
 int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t* indptr,
@@ -580,7 +745,7 @@ int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t*
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B); GO_PTR(fn, dy);
   // kernel_0 (graphop_kernel.cu:61-73): dA[row] += sum_k dy[eid[k], j/d] * B[eid[k], j%d]
   GO_TRY(launch_spmm<true>("node_mul_edge_bwd_dA", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                           (const i64*)eid, dy, B, dA, n_chunks, n_edges, n_edges, h, d, st));
+                           (const i64*)eid, dy, B, dA, n_chunks, n_edges, n_edges, h, d, nullptr, st));
   // kernel_1 (:79-94): dB[eid[k], j] = sum_ki dy[eid[k], ki] * A[row, ki, j]
   const unsigned nb = (unsigned)ceil_div(n_chunks, kGenericWavesPerBlock);
   if (dtype == GRAPHOP_F32)

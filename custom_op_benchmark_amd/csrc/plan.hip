@@ -1,6 +1,9 @@
 // Plan construction + partition_csr kernels (setup path; integer work, bit-exact).
 #include <hipcub/hipcub.hpp>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace graphop {
@@ -124,6 +127,60 @@ __global__ void k_narrow(const i64* __restrict__ src, int32_t* __restrict__ dst,
   for (; i < n; i += stride) dst[i] = (int32_t)src[i];
 }
 
+// neighbour ids ascend inside every row segment?  (needed by the window sweep)
+__global__ void k_plan_sorted_ids(const i64* __restrict__ row, const i64* __restrict__ indptr,
+                                  const i64* __restrict__ indices, i64 n_chunks,
+                                  PlanStats* __restrict__ st) {
+  i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  i64 bad = 0;
+  for (; c < n_chunks; c += stride) {
+    const i64 a = indptr[c], b = indptr[c + 1];
+    for (i64 k = a; k + 1 < b; ++k) bad += indices[k] > indices[k + 1];
+    // a row's chunks are adjacent and contiguous in slot space (row_owned): check the seam
+    if (b > a && c + 1 < n_chunks && row[c + 1] == row[c] && indptr[c + 2] > b)
+      bad += indices[b - 1] > indices[b];
+  }
+  if (bad) atomicAdd((unsigned long long*)&st->unsorted_ids, (unsigned long long)bad);
+}
+
+// ---- window sweep construction ----------------------------------------------------------------------
+__global__ void k_seg_eptr(const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+                           i64 n_seg, i64* __restrict__ seg_eptr) {
+  i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; s <= n_seg; s += stride) seg_eptr[s] = indptr[seg_chunk[s]];
+}
+
+// vrows = partition_csr(seg_eptr, T): vr_seg[v] (segment), vr_ptr[v] (first slot); then
+// wp[w*V + v] = first slot of vrow v with neighbour id >= w*win_cols (binary search, ids ascend).
+__global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restrict__ vr_ptr,
+                             const i64* __restrict__ seg_chunk, const i64* __restrict__ row,
+                             const int32_t* __restrict__ idx32, i64 V, int W, i64 win_cols,
+                             int* __restrict__ vr_row, int* __restrict__ wp) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  const i64 total = V * (W + 1);
+  for (; i < total; i += stride) {
+    const i64 w = i / V, v = i - w * V;
+    const i64 e0 = vr_ptr[v], e1 = vr_ptr[v + 1];
+    if (w == 0) vr_row[v] = (int)row[seg_chunk[vr_seg[v]]];
+    i64 pos;
+    if (w == 0) pos = e0;
+    else if (w == W) pos = e1;
+    else {
+      const i64 bound = w * win_cols;
+      i64 lo = e0, hi = e1;  // first k in [e0, e1) with idx[k] >= bound
+      while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if ((i64)idx32[mid] < bound) lo = mid + 1; else hi = mid;
+      }
+      pos = lo;
+    }
+    wp[i] = (int)pos;
+  }
+}
+
 struct DevBuf {  // frees on scope exit (setup path only)
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -241,6 +298,16 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
     info.full_coverage = E == 0;
   }
 
+  p->sorted_in_rows = 0;
+  if (C > 0 && indices && info.row_owned) {
+    hipLaunchKernelGGL(k_plan_sorted_ids, dim3(grid_for(C, kBlock, 8192)), dim3(kBlock), 0, st,
+                       row, indptr, indices, C, stats);
+    GO_LAUNCH_CHECK();
+    GO_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipStreamSynchronize(st));
+    p->sorted_in_rows = h.unsorted_ids == 0;
+  }
+
   // 32-bit mirrors of the slot arrays (halves index traffic of every pass)
   const bool want32 = env_int("GRAPHOP_IDX32", 1) != 0;
   if (want32 && E > 0 && E < 0x7fffffffLL && h.max_index < 0x7fffffffLL) {
@@ -260,6 +327,68 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
     info.has_idx32 = 1;
   }
   return GRAPHOP_OK;
+}
+
+// Build (or fetch) the window-sweep structure for W windows of win_cols ids and vrows of <= T slots.
+int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, const Sweep** out) {
+  auto* mu = (std::mutex*)p->sweep_mu;
+  auto* vec = (std::vector<Sweep>*)p->sweeps;
+  std::lock_guard<std::mutex> lk(*mu);
+  for (auto& s : *vec)
+    if (s.W == W && s.win_cols == win_cols && s.T == T) { *out = &s; return GRAPHOP_OK; }
+  const i64 S = p->info.n_segments, E = p->info.n_edges;
+  GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E < 0x7fffffffLL && S > 0,
+               "plan_get_sweep: plan is not sweepable");
+  const i64* indptr = (const i64*)p->indptr;
+  DevBuf seg_eptr, first, vr_seg, vr_ptr;
+  GO_HIP(hipMalloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1)));
+  GO_HIP(hipMalloc(&first.p, sizeof(i64) * (size_t)(S + 1)));
+  hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
+                     (const i64*)p->seg_chunk, indptr, S, (i64*)seg_eptr.p);
+  GO_LAUNCH_CHECK();
+  int rc = partition_count((const i64*)seg_eptr.p, S, T, (i64*)first.p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  i64 V = 0;
+  GO_HIP(hipMemcpyAsync(&V, (i64*)first.p + S, sizeof(i64), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+  GO_CHECK_ARG(V > 0 && V < 0x7fffffffLL && V * (W + 1) < (i64)1 << 40, "plan_get_sweep: size");
+  GO_HIP(hipMalloc(&vr_seg.p, sizeof(i64) * (size_t)V));
+  GO_HIP(hipMalloc(&vr_ptr.p, sizeof(i64) * (size_t)(V + 1)));
+  rc = partition_fill((const i64*)seg_eptr.p, (const i64*)first.p, S, T, V, (i64*)vr_seg.p,
+                      (i64*)vr_ptr.p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  Sweep s;
+  s.W = W; s.win_cols = win_cols; s.T = T; s.V = (int)V;
+  GO_HIP(hipMalloc((void**)&s.vr_row, sizeof(int) * (size_t)V));
+  if (hipMalloc((void**)&s.wp, sizeof(int) * (size_t)(V * (W + 1))) != hipSuccess) {
+    (void)hipFree(s.vr_row);
+    set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(V * (W + 1)));
+    return GRAPHOP_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_sweep_fill, dim3(grid_for(V * (W + 1), kBlock, 16384)), dim3(kBlock), 0, st,
+                     (const i64*)vr_seg.p, (const i64*)vr_ptr.p, (const i64*)p->seg_chunk,
+                     (const i64*)p->row, (const int32_t*)p->idx32, V, W, win_cols, s.vr_row, s.wp);
+  GO_LAUNCH_CHECK();
+  GO_HIP(hipStreamSynchronize(st));
+  vec->push_back(s);
+  *out = &vec->back();
+  return GRAPHOP_OK;
+}
+
+void plan_free_sweeps(graphop_plan* p) {
+  auto* vec = (std::vector<Sweep>*)p->sweeps;
+  if (vec) {
+    for (auto& s : *vec) { (void)hipFree(s.vr_row); (void)hipFree(s.wp); }
+    delete vec;
+  }
+  delete (std::mutex*)p->sweep_mu;
+  p->sweeps = nullptr; p->sweep_mu = nullptr;
+}
+
+void plan_init_sweeps(graphop_plan* p) {
+  p->sweeps = new std::vector<Sweep>();
+  ((std::vector<Sweep>*)p->sweeps)->reserve(16);   // pointers handed out must stay valid
+  p->sweep_mu = new std::mutex();
 }
 
 }  // namespace graphop

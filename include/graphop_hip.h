@@ -79,6 +79,12 @@ typedef struct graphop_plan_info {
 GRAPHOP_API int graphop_abi_version(void);
 GRAPHOP_API const char* graphop_last_error(void);
 
+/* ---- tuning knobs (also read once from the environment as GRAPHOP_<KEY>) ----------------------
+ * keys: sddmm_cpg, spmm_cpg (chunks per lane group of the chunk drivers), force_generic,
+ * sweep (0/1), window_kb, max_windows, sweep_min_kb, sweep_bpc, sweep_k, vrow_t.  Not
+ * thread-safe against concurrent op calls; results never depend on them. */
+GRAPHOP_API int graphop_tune(const char* key, int value);
+
 /* ---- per-kernel timing (measurement aid, off by default) -----------------------------------
  * When enabled, every hot-path kernel launch is bracketed by two hipEvents recorded on the
  * launch stream.  graphop_profile_read synchronises them, aggregates per pass tag
