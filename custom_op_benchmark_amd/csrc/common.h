@@ -68,8 +68,11 @@ struct Sweep {
   int T = 0;            // longest vrow (rows longer than T slots are cut into pieces)
   int V = 0;            // number of vrows
   int* vr_row = nullptr;  // [V] owning row id
-  int* wp = nullptr;      // [(W+1)*V] window boundaries (slot indices)
+  int* wp_lo = nullptr;   // [W*V] first slot of vrow v inside window w
+  int* wp_hi = nullptr;   // [W*V] one past its last slot inside window w
+  int* sync = nullptr;    // [kSweepSyncInts] pacing counters (zeroed before every sweep launch)
 };
+constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
 }  // namespace graphop
 
 struct graphop_plan {

@@ -67,6 +67,7 @@ struct Tuning {
   int sweep_bpc;        // resident blocks per CU for the sweep drivers
   int sweep_k;          // vrows per lane group (0 = auto)
   int vrow_t;           // vrow length cap (0 = auto from the mean row length)
+  int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -76,6 +77,7 @@ struct Tuning {
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
+    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -170,16 +172,30 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
   if (K > L) K = L;
   const int gpb = kFastBlock / L;
-  i64 blocks = (i64)t.n_cu * t.sweep_bpc;
-  i64 rounds = ceil_div(sw->V, blocks * gpb * K);
+  const int bpc = t.sweep_bpc < 1 ? 1 : (t.sweep_bpc > kSweepBlocksPerCu ? kSweepBlocksPerCu : t.sweep_bpc);
+  // grid: a multiple of 8 workgroups; XCD slot x (= blockIdx % 8) owns vrows [x*vx, (x+1)*vx)
+  i64 blocks = (i64)t.n_cu * bpc;
+  blocks -= blocks % 8;
+  int slots = 8;
+  i64 vx = ceil_div(ceil_div(sw->V, slots), K) * K;
+  i64 rounds = ceil_div(vx, (blocks / slots) * gpb * K);
   if (rounds <= 1) {
     rounds = 1;
-    blocks = ceil_div(ceil_div(sw->V, K), gpb);
+    blocks = ceil_div(ceil_div(vx, K), gpb) * slots;
   }
-  out->view.wp = sw->wp;
+  out->view.xcd_slots = slots;
+  out->view.vx = (int)vx;
+  out->view.wp_lo = sw->wp_lo;
+  out->view.wp_hi = sw->wp_hi;
   out->view.vr_row = sw->vr_row;
   out->view.idx32 = plan->idx32;
   out->view.eid32 = plan->eid32;
+  const i64 sync_ints = 64LL * (8 + 16 * rounds * sw->W);  // kSyncStride * (kSyncXcds + 2 * xcds * steps)
+  const bool paced = t.sweep_drift > 0 && sync_ints <= kSweepSyncInts;
+  out->view.sync = paced ? sw->sync : nullptr;
+  out->view.drift = paced ? t.sweep_drift : 0;
+  if (paced && hipMemsetAsync(sw->sync, 0, sizeof(int) * (size_t)sync_ints, st) != hipSuccess)
+    return -GRAPHOP_ERR_HIP;
   out->view.V = sw->V;
   out->view.W = sw->W;
   out->view.K = K;
@@ -452,7 +468,7 @@ int graphop_tune(const char* key, int value) {
       {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
-      {"vrow_t", &t.vrow_t}};
+      {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;

@@ -255,20 +255,350 @@ __global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
   if (dirty) atomic_flush<L, NV>(out, cur_row, acc, l);
 }
 
+
+// ---- STRIP inner loops (window-sweep drivers) -----------------------------------------------------
+// A strip is what one lane group does in one window: lane k < nv owns granule k = slots
+// [lo_l, lo_l + n_l) of its vrow k.  The K granules are walked as ONE flat slot list in full
+// batches of SB slots (no per-granule round-up), the ids of the next batch are fetched while the
+// current batch's rows are in flight, and all SB rows of a batch are requested before any is used.
+template <int L, int NV>
+struct StripCfg {
+  static constexpr int kMaxBatch = NV == 1 ? 16 : (NV == 2 ? 8 : 4);   // 64 VGPRs of rows in flight
+  static constexpr int SB = L < kMaxBatch ? L : kMaxBatch;
+};
+
+struct StripMap {   // flat slot j of the strip -> (granule k, slot e); all group-local
+  int P;            // inclusive prefix of granule lengths (lane k)
+  int Pex;          // exclusive prefix
+  int lo;           // granule start (lane k)
+  int total;
+  template <int L>
+  __device__ __forceinline__ void init(int lo_l, int n_l, int l) {
+    lo = lo_l;
+    P = n_l;
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) {
+      const int t = __shfl_up(P, off, L);
+      if (l >= off) P += t;
+    }
+    Pex = P - n_l;
+    total = __shfl(P, L - 1, L);
+  }
+  // granule of flat slot j (j < total): number of granules whose inclusive prefix is <= j
+  template <int L>
+  __device__ __forceinline__ void locate(int j, int& k, int& e) const {
+    k = 0;
+#pragma unroll
+    for (int step = L / 2; step >= 1; step >>= 1) {
+      const int pv = __shfl(P, k + step - 1, L);
+      if (pv <= j) k += step;
+    }
+    e = __shfl(lo, k, L) + (j - __shfl(Pex, k, L));
+  }
+};
+
+// SDDMM strip: y[eid[e]*h + head] = <A_k, B[idx[e]]> ; A rows of the group's K vrows are in LDS.
+template <int L, int NV, bool H1, bool EID_ID>
+__device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, int lo_l, int n_l,
+                                            const int* __restrict__ eid32,
+                                            const int* __restrict__ idx32,
+                                            const float* __restrict__ B, float* __restrict__ y,
+                                            int h, int d4, int l) {
+  constexpr int SB = StripCfg<L, NV>::SB;
+  constexpr i64 F4 = (i64)L * NV;
+  StripMap m;
+  m.init<L>(lo_l, n_l, l);
+  if (m.total == 0) return;
+  float4 a[NV];
+  int k_cur = -1;
+  // prefetch batch 0
+  int nk = 0, ne = -1, nsrc = 0;
+  {
+    const int j = l;
+    int e;
+    m.locate<L>(j < m.total ? j : m.total - 1, nk, e);   // every lane takes part in the shuffles
+    if (l < SB && j < m.total) {
+      ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+      nsrc = __builtin_nontemporal_load(idx32 + e);
+    }
+  }
+  for (int jb = 0; jb < m.total; jb += SB) {
+    const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
+    const int my_k = nk, my_e = ne, my_src = nsrc;
+    float4 b[SB][NV];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int tt = u < nb ? u : (nb - 1);
+      const i64 src = __shfl(my_src, tt, L);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) b[u][v] = ld4(B, src * F4 + v * L + l);
+    }
+    // ids of the next batch (issued after the row requests so they stay in flight behind them)
+    ne = -1;
+    {
+      const int j = jb + SB + l;
+      int e;
+      m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
+      if (l < SB && j < m.total) {
+        ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+        nsrc = __builtin_nontemporal_load(idx32 + e);
+      }
+    }
+    float res = 0.f;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const bool live = u < nb;
+      const int tt = live ? u : (nb - 1);
+      const int kt = __shfl(my_k, tt, L);
+      if (kt != k_cur) {   // group-uniform
+#pragma unroll
+        for (int v = 0; v < NV; ++v) a[v] = rowsA[(kt * NV + v) * L + l];
+        k_cur = kt;
+      }
+      if constexpr (H1) {
+        float p = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) p += dot4(a[v], b[u][v]);
+        p = group_sum<L>(p);
+        if (l == u) res = p;
+      } else {
+        const i64 e = __shfl(my_e, tt, L);
+        if (d4 >= L) {
+          const int sph = d4 / L;
+          float acc = 0.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            acc += dot4(a[v], b[u][v]);
+            if ((v + 1) % sph == 0) {
+              const float sum = group_sum<L>(acc);
+              if (live && l == 0) y[e * h + v / sph] = sum;
+              acc = 0.f;
+            }
+          }
+        } else {
+          const int hps = L / d4;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const float sum = group_sum_rt(dot4(a[v], b[u][v]), d4);
+            if (live && (l % d4) == 0) y[e * h + v * hps + l / d4] = sum;
+          }
+        }
+      }
+    }
+    if constexpr (H1) {
+      if (l < nb) __builtin_nontemporal_store(res, y + my_e);
+    }
+  }
+}
+
+// SpMM strip: rowsAcc[k] += sum_e w[eid[e]*h + head] * X[idx[e]] ; partial sums of the K vrows
+// live in LDS across windows, the running granule sum in registers.
+template <int L, int NV, bool H1, bool EID_ID>
+__device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_l, int n_l,
+                                           const int* __restrict__ eid32,
+                                           const int* __restrict__ idx32,
+                                           const float* __restrict__ w,
+                                           const float* __restrict__ X, int h,
+                                           const int (&hv)[NV], int l) {
+  constexpr int SB = StripCfg<L, NV>::SB;
+  constexpr i64 F4 = (i64)L * NV;
+  StripMap m;
+  m.init<L>(lo_l, n_l, l);
+  if (m.total == 0) return;
+  float4 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k_cur = -1;
+  auto spill = [&]() {
+    if (k_cur >= 0) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float4 o = rowsAcc[(k_cur * NV + v) * L + l];
+        o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+        rowsAcc[(k_cur * NV + v) * L + l] = o;
+        acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  int nk = 0, ne = 0, nsrc = 0;
+  float nw = 0.f;
+  {
+    const int j = l;
+    int e;
+    m.locate<L>(j < m.total ? j : m.total - 1, nk, e);   // every lane takes part in the shuffles
+    if (l < SB && j < m.total) {
+      ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+      nsrc = __builtin_nontemporal_load(idx32 + e);
+      if constexpr (H1) nw = EID_ID ? __builtin_nontemporal_load(w + ne) : w[ne];
+    }
+  }
+  for (int jb = 0; jb < m.total; jb += SB) {
+    const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
+    const int my_k = nk, my_e = ne, my_src = nsrc;
+    const float my_w = nw;
+    float4 x[SB][NV];
+    float wt[H1 ? 1 : SB][H1 ? 1 : NV];   // per-head weights are loads and must be issued early
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const bool live = u < nb;
+      const int tt = live ? u : (nb - 1);
+      const i64 src = __shfl(my_src, tt, L);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) x[u][v] = ld4(X, src * F4 + v * L + l);
+      if constexpr (!H1) {
+        const i64 e = __shfl(my_e, tt, L);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) wt[u][v] = live ? w[e * h + hv[v]] : 0.f;
+      }
+    }
+    nw = 0.f;
+    {
+      const int j = jb + SB + l;
+      int e;
+      m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
+      if (l < SB && j < m.total) {
+        ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+        nsrc = __builtin_nontemporal_load(idx32 + e);
+        if constexpr (H1) nw = EID_ID ? __builtin_nontemporal_load(w + ne) : w[ne];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int tt = u < nb ? u : (nb - 1);
+      const int kt = __shfl(my_k, tt, L);
+      if (kt != k_cur) {   // group-uniform
+        spill();
+        k_cur = kt;
+      }
+      float w1 = 0.f;
+      if constexpr (H1) {
+        w1 = __shfl(my_w, tt, L);
+        if (u >= nb) w1 = 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float ww = H1 ? w1 : wt[H1 ? 0 : u][H1 ? 0 : v];
+        acc[v].x = fmaf(ww, x[u][v].x, acc[v].x);
+        acc[v].y = fmaf(ww, x[u][v].y, acc[v].y);
+        acc[v].z = fmaf(ww, x[u][v].z, acc[v].z);
+        acc[v].w = fmaf(ww, x[u][v].w, acc[v].w);
+      }
+    }
+  }
+  spill();
+}
+
 // ---- WINDOW-SWEEP drivers (plan) -----------------------------------------------------------------
-// vrow v = slots [wp[v], wp[W*V + v]) of row vr_row[v]; wp[w*V + v] = first slot of vrow v whose
-// neighbour id is >= w * win_cols (ids ascend inside a row).  Group g of round r owns vrows
+// vrow v = (a piece of) row vr_row[v]; inside window w it owns slots [wp_lo[w*V+v], wp_hi[w*V+v])
+// whose neighbour ids lie in [w*win_cols, (w+1)*win_cols).  A row longer than T slots is cut into
+// P pieces that each take 1/P of the row's slots in EVERY window.  Group g of round r owns vrows
 // [(r*n_groups + g)*K, +K).  LDS holds the K rows (A rows / partial sums) of every group.
+constexpr int kSweepBlocksPerCu = 4;   // co-resident 256-thread workgroups per CU the sweep kernels
+                                       // are compiled for (<= 128 VGPRs, 32 KB LDS each)
 struct SweepView {
-  const int* wp;      // [(W+1) * V]
+  const int* wp_lo;   // [W * V]
+  const int* wp_hi;   // [W * V]
   const int* vr_row;  // [V]
   const int* idx32;   // [E]
   const int* eid32;   // [E] or nullptr when eid is the identity
+  int* sync;          // [rounds * W] arrival counters, zeroed before the launch (nullptr = free-running)
   int V, W, K, rounds;
+  int drift;          // a workgroup may run at most `drift` windows ahead of the slowest one
+  int xcd_slots;      // grid is a multiple of this; workgroup b serves XCD slot b % xcd_slots
+  int vx;             // vrows per XCD slot (multiple of K)
+};
+
+// Soft pacing between the workgroups of one sweep launch, per XCD (each XCD has its own L2, so
+// only workgroups sharing an XCD need to walk the windows together).  Counters are sharded by the
+// hardware XCC id: sync[0..7] = workgroups registered per XCD, then one 256-B line per
+// (XCD, step).  One thread per workgroup signals / polls; the other waves wait at a barrier.
+// It only keeps the gather window L2-resident (speed); results never depend on it: the spin is
+// bounded and a workgroup that times out stops waiting for good, so a grid that is not fully
+// co-resident cannot hang.
+constexpr int kSyncStride = 64;   // ints between counters: one 256-B line each
+constexpr int kSyncXcds = 8;
+// Layout of SweepView::sync (ints, all zero at launch):
+//   [xcc * kSyncStride]                                   workgroups registered on XCD xcc
+//   [(kSyncXcds + (xcc*steps + s)*2 + 0) * kSyncStride]    arrivals at the end of step s
+//   [(kSyncXcds + (xcc*steps + s)*2 + 1) * kSyncStride]    1 once every registered workgroup arrived
+// Arrivals are returning agent-scope atomics (memory side, ~12 ns each per line); the workgroup
+// whose add completes the count publishes the release word, which the others poll with relaxed
+// agent loads served by their own XCD's L2 (writer and readers share that L2).
+struct SweepPacer {
+  int* ctr;        // this XCD's (arrivals, released) pairs
+  int* reg;        // this XCD's registration counter
+  int drift;
+  bool active;
+  int* flag;       // LDS word: 1 = keep pacing, 0 = gave up
+  __device__ __forceinline__ SweepPacer(const SweepView& s, int* lds_flag)
+      : ctr(nullptr), reg(nullptr), drift(s.drift), active(s.sync != nullptr && s.drift > 0),
+        flag(lds_flag) {
+    if (!active) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= kSyncXcds - 1;
+    const int steps = s.rounds * s.W;
+    reg = s.sync + (i64)xcc * kSyncStride;
+    ctr = s.sync + (i64)kSyncStride * (kSyncXcds + 2 * (i64)xcc * steps);
+    if (threadIdx.x == 0) {
+      *flag = 1;
+      __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+  // called by every thread of the workgroup after finishing `done_step` (or -1 before step 0);
+  // returns once the workgroup may start step done_step + 1
+  __device__ __forceinline__ void step_done_and_wait(int done_step) {
+    if (!active) return;
+    __syncthreads();                       // every wave of the workgroup finished done_step
+    if (threadIdx.x == 0 && *flag) {
+      if (done_step >= 0) {
+        int* c = ctr + (i64)done_step * 2 * kSyncStride;
+        const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 >= n)
+          __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int need = done_step + 1 - drift;   // step that everybody must have finished
+      if (need >= 0) {
+        const int* rel = ctr + ((i64)need * 2 + 1) * kSyncStride;
+        int it = 0;
+        while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++it > 8000) { *flag = 0; break; }   // several ms: give up pacing for good
+        }
+      }
+    }
+    __syncthreads();
+    if (*flag == 0) active = false;
+  }
+};
+
+// Which vrows a lane group owns.  Workgroups b, b+8, ... share an XCD under the observed
+// round-robin placement (speed only): XCD slot x = b % 8 owns the CONTIGUOUS vrow range
+// [x*vx, (x+1)*vx), so neighbouring rows -- whose per-slot scalars share cache lines in the
+// transposed passes -- are walked by workgroups behind the same L2 at the same time.
+struct SweepOwner {
+  i64 base, end, stride_groups, group;
+  __device__ __forceinline__ SweepOwner(const SweepView& s, int gpb, int g_in_blk) {
+    const int slots = s.xcd_slots;                       // 8, or 1 for tiny grids
+    const i64 x = blockIdx.x % slots, lb = blockIdx.x / slots;
+    const i64 blocks_per_slot = gridDim.x / slots;
+    base = x * (i64)s.vx;
+    end = base + s.vx < s.V ? base + s.vx : s.V;
+    stride_groups = blocks_per_slot * gpb;
+    group = lb * gpb + g_in_blk;
+  }
+  __device__ __forceinline__ i64 first_vrow(int r, int K) const {
+    return base + ((i64)r * stride_groups + group) * K;
+  }
+  __device__ __forceinline__ int count(i64 v0, int K) const {
+    return v0 >= end ? 0 : ((end - v0) < K ? (int)(end - v0) : K);
+  }
 };
 
 template <int L, int NV, bool H1, bool EID_ID>
-__global__ __launch_bounds__(kFastBlock) void k_sddmm_sweep_f32(
+__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
     int h, int d4) {
   extern __shared__ float4 lds[];
@@ -276,38 +606,32 @@ __global__ __launch_bounds__(kFastBlock) void k_sddmm_sweep_f32(
   constexpr i64 F4 = (i64)L * NV;
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
-  const i64 n_groups = (i64)gridDim.x * GPB;
-  const i64 gid = (i64)blockIdx.x * GPB + g_in_blk;
   float4* mine = lds + (i64)g_in_blk * s.K * F4;  // [K][NV][L]
+  __shared__ int pace_flag;
+  SweepPacer pacer(s, &pace_flag);
+  const SweepOwner own(s, GPB, g_in_blk);
   for (int r = 0; r < s.rounds; ++r) {
-    const i64 v0 = ((i64)r * n_groups + gid) * s.K;
-    if (v0 >= s.V) break;
-    const int nv = (s.V - v0) < s.K ? (int)(s.V - v0) : s.K;
+    const i64 v0 = own.first_vrow(r, s.K);
+    const int nv = own.count(v0, s.K);
     for (int k = 0; k < nv; ++k) {
       const i64 row = s.vr_row[v0 + k];
 #pragma unroll
       for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
     }
     for (int w = 0; w < s.W; ++w) {
+      pacer.step_done_and_wait(r * s.W + w - 1);
       int lo_l = 0, hi_l = 0;
       if (l < nv) {
-        lo_l = s.wp[(i64)w * s.V + v0 + l];
-        hi_l = s.wp[(i64)(w + 1) * s.V + v0 + l];
+        lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
+        hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
-      for (int k = 0; k < nv; ++k) {
-        const int lo = __shfl(lo_l, k, L), hi = __shfl(hi_l, k, L);
-        if (hi <= lo) continue;
-        float4 a[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) a[v] = mine[(k * NV + v) * L + l];
-        sddmm_range<L, NV, H1, false, EID_ID, true, int>(a, lo, hi, s.eid32, s.idx32, B, y, h, d4, l);
-      }
+      sddmm_strip<L, NV, H1, EID_ID>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
     }
   }
 }
 
 template <int L, int NV, bool H1, bool EID_ID>
-__global__ __launch_bounds__(kFastBlock) void k_spmm_sweep_f32(
+__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f32(
     SweepView s, const float* __restrict__ wgt, const float* __restrict__ X,
     float* __restrict__ out, int h, int d4) {
   extern __shared__ float4 lds[];
@@ -315,39 +639,33 @@ __global__ __launch_bounds__(kFastBlock) void k_spmm_sweep_f32(
   constexpr i64 F4 = (i64)L * NV;
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
-  const i64 n_groups = (i64)gridDim.x * GPB;
-  const i64 gid = (i64)blockIdx.x * GPB + g_in_blk;
   float4* mine = lds + (i64)g_in_blk * s.K * F4;
   int hv[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) hv[v] = H1 ? 0 : (v * L + l) / d4;
+  __shared__ int pace_flag;
+  SweepPacer pacer(s, &pace_flag);
+  const SweepOwner own(s, GPB, g_in_blk);
   for (int r = 0; r < s.rounds; ++r) {
-    const i64 v0 = ((i64)r * n_groups + gid) * s.K;
-    if (v0 >= s.V) break;
-    const int nv = (s.V - v0) < s.K ? (int)(s.V - v0) : s.K;
+    const i64 v0 = own.first_vrow(r, s.K);
+    const int nv = own.count(v0, s.K);
     for (int k = 0; k < nv; ++k)
 #pragma unroll
       for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt_l = 0;        // lane k: slots vrow k received over all windows
     for (int w = 0; w < s.W; ++w) {
+      pacer.step_done_and_wait(r * s.W + w - 1);
       int lo_l = 0, hi_l = 0;
       if (l < nv) {
-        lo_l = s.wp[(i64)w * s.V + v0 + l];
-        hi_l = s.wp[(i64)(w + 1) * s.V + v0 + l];
+        lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
+        hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
-      for (int k = 0; k < nv; ++k) {
-        const int lo = __shfl(lo_l, k, L), hi = __shfl(hi_l, k, L);
-        if (hi <= lo) continue;
-        float4 acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = mine[(k * NV + v) * L + l];
-        spmm_range<L, NV, H1, EID_ID, true, int>(acc, lo, hi, s.eid32, s.idx32, wgt, X, h, hv, l);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = acc[v];
-      }
+      cnt_l += hi_l - lo_l;
+      spmm_strip<L, NV, H1, EID_ID>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
     }
     // pieces of one (long) row may live in several groups: merge with float atomics
     for (int k = 0; k < nv; ++k) {
-      if (s.wp[v0 + k] == s.wp[(i64)s.W * s.V + v0 + k]) continue;
+      if (__shfl(cnt_l, k, L) == 0) continue;
       float4 acc[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] = mine[(k * NV + v) * L + l];

@@ -152,19 +152,17 @@ __global__ void k_seg_eptr(const i64* __restrict__ seg_chunk, const i64* __restr
   for (; s <= n_seg; s += stride) seg_eptr[s] = indptr[seg_chunk[s]];
 }
 
-// vrows = partition_csr(seg_eptr, T): vr_seg[v] (segment), vr_ptr[v] (first slot); then
-// wp[w*V + v] = first slot of vrow v with neighbour id >= w*win_cols (binary search, ids ascend).
-__global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restrict__ vr_ptr,
-                             const i64* __restrict__ seg_chunk, const i64* __restrict__ row,
-                             const int32_t* __restrict__ idx32, i64 V, int W, i64 win_cols,
-                             int* __restrict__ vr_row, int* __restrict__ wp) {
+// Row-window boundaries: rw[w*S + s] = first slot of segment s whose neighbour id is >= w*win_cols
+// (ids ascend inside a row; rw[0] = segment start, rw[W] = segment end).
+__global__ void k_sweep_row_windows(const i64* __restrict__ seg_eptr,
+                                    const int32_t* __restrict__ idx32, i64 S, int W, i64 win_cols,
+                                    int* __restrict__ rw) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 stride = (i64)gridDim.x * blockDim.x;
-  const i64 total = V * (W + 1);
+  const i64 total = S * (W + 1);
   for (; i < total; i += stride) {
-    const i64 w = i / V, v = i - w * V;
-    const i64 e0 = vr_ptr[v], e1 = vr_ptr[v + 1];
-    if (w == 0) vr_row[v] = (int)row[seg_chunk[vr_seg[v]]];
+    const i64 w = i / S, s = i - w * S;
+    const i64 e0 = seg_eptr[s], e1 = seg_eptr[s + 1];
     i64 pos;
     if (w == 0) pos = e0;
     else if (w == W) pos = e1;
@@ -177,7 +175,34 @@ __global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restri
       }
       pos = lo;
     }
-    wp[i] = (int)pos;
+    rw[i] = (int)pos;
+  }
+}
+
+// vrows: a segment of len slots becomes P = ceil(len / T) pieces (vr_seg / first_v come from
+// partition_csr(seg_eptr, T)).  Piece p takes the p-th 1/P of the row's slots INSIDE EVERY WINDOW
+// (not a contiguous 1/P of the row), so a long row loads all windows evenly:
+//   wp_lo[w*V + v] = rw[w][s] + min(len_w, p*q),  wp_hi = rw[w][s] + min(len_w, (p+1)*q),
+//   len_w = rw[w+1][s] - rw[w][s],  q = ceil(len_w / P).
+__global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restrict__ first_v,
+                             const i64* __restrict__ seg_chunk, const i64* __restrict__ row,
+                             const int* __restrict__ rw, i64 S, i64 V, int W,
+                             int* __restrict__ vr_row, int* __restrict__ wp_lo,
+                             int* __restrict__ wp_hi) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  const i64 total = V * W;
+  for (; i < total; i += stride) {
+    const i64 w = i / V, v = i - w * V;
+    const i64 s = vr_seg[v];
+    const i64 p = v - first_v[s], P = first_v[s + 1] - first_v[s];
+    if (w == 0) vr_row[v] = (int)row[seg_chunk[s]];
+    const i64 a = rw[w * S + s], len = rw[(w + 1) * S + s] - a;
+    const i64 q = (len + P - 1) / P;
+    const i64 lo = p * q < len ? p * q : len;
+    const i64 hi = (p + 1) * q < len ? (p + 1) * q : len;
+    wp_lo[i] = (int)(a + lo);
+    wp_hi[i] = (int)(a + hi);
   }
 }
 
@@ -336,6 +361,7 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   std::lock_guard<std::mutex> lk(*mu);
   for (auto& s : *vec)
     if (s.W == W && s.win_cols == win_cols && s.T == T) { *out = &s; return GRAPHOP_OK; }
+  GO_CHECK_ARG(vec->size() < 16, "plan_get_sweep: too many window geometries for one plan");
   const i64 S = p->info.n_segments, E = p->info.n_edges;
   GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E < 0x7fffffffLL && S > 0,
                "plan_get_sweep: plan is not sweepable");
@@ -357,17 +383,26 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   rc = partition_fill((const i64*)seg_eptr.p, (const i64*)first.p, S, T, V, (i64*)vr_seg.p,
                       (i64*)vr_ptr.p, st);
   if (rc != GRAPHOP_OK) return rc;
+  DevBuf rw;
+  GO_HIP(hipMalloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1))));
+  hipLaunchKernelGGL(k_sweep_row_windows, dim3(grid_for(S * (W + 1), kBlock, 16384)), dim3(kBlock),
+                     0, st, (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, win_cols,
+                     (int*)rw.p);
+  GO_LAUNCH_CHECK();
   Sweep s;
   s.W = W; s.win_cols = win_cols; s.T = T; s.V = (int)V;
-  GO_HIP(hipMalloc((void**)&s.vr_row, sizeof(int) * (size_t)V));
-  if (hipMalloc((void**)&s.wp, sizeof(int) * (size_t)(V * (W + 1))) != hipSuccess) {
-    (void)hipFree(s.vr_row);
-    set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(V * (W + 1)));
+  const size_t wp_bytes = sizeof(int) * (size_t)(V * W);
+  if (hipMalloc((void**)&s.vr_row, sizeof(int) * (size_t)V) != hipSuccess ||
+      hipMalloc((void**)&s.wp_lo, wp_bytes) != hipSuccess ||
+      hipMalloc((void**)&s.wp_hi, wp_bytes) != hipSuccess ||
+      hipMalloc((void**)&s.sync, sizeof(int) * kSweepSyncInts) != hipSuccess) {
+    (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
+    set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
     return GRAPHOP_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_sweep_fill, dim3(grid_for(V * (W + 1), kBlock, 16384)), dim3(kBlock), 0, st,
-                     (const i64*)vr_seg.p, (const i64*)vr_ptr.p, (const i64*)p->seg_chunk,
-                     (const i64*)p->row, (const int32_t*)p->idx32, V, W, win_cols, s.vr_row, s.wp);
+  hipLaunchKernelGGL(k_sweep_fill, dim3(grid_for(V * W, kBlock, 16384)), dim3(kBlock), 0, st,
+                     (const i64*)vr_seg.p, (const i64*)first.p, (const i64*)p->seg_chunk,
+                     (const i64*)p->row, (const int*)rw.p, S, V, W, s.vr_row, s.wp_lo, s.wp_hi);
   GO_LAUNCH_CHECK();
   GO_HIP(hipStreamSynchronize(st));
   vec->push_back(s);
@@ -378,7 +413,9 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
 void plan_free_sweeps(graphop_plan* p) {
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
-    for (auto& s : *vec) { (void)hipFree(s.vr_row); (void)hipFree(s.wp); }
+    for (auto& s : *vec) {
+      (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
+    }
     delete vec;
   }
   delete (std::mutex*)p->sweep_mu;
