@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--cpu-sample-edges", type=int, default=3_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single-GPU rehearsal: build rank 0's shard of a WORLD-way partition and time its "
+                         "local compute (collectives replaced by local copies); not a headline number")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -148,7 +151,13 @@ def main():
 
     # ---- setup (not timed as part of a step; reported) -------------------------------------------
     t_setup = time.perf_counter()
-    if world == 1:
+    if world == 1 and args.emulate_world > 1:
+        from custom_op_benchmark_amd import dist as gdist
+        runner = gdist.ShardedAttention.synthetic(N, E, args.emulate_world, 0, dev, alpha=args.alpha,
+                                                  seed=args.seed, chunk_size=args.chunk_size, emulate=True)
+        g = runner.graph
+        n_rows, n_cols = g.n_src, g.n_dst
+    elif world == 1:
         g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev)
         runner = None
         n_rows, n_cols = g.n_src, g.n_dst
@@ -160,7 +169,7 @@ def main():
         n_rows, n_cols = g.n_src, g.n_dst
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1 + rank)
     shp = (lambda n: (n, d) if h == 1 else (n, h, d))
-    n_own = N if world == 1 else runner.n_own
+    n_own = N if runner is None else runner.n_own
     Q = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
     K = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
     V = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
@@ -259,11 +268,12 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s-shape Chung-Lu(alpha=%.2f) graph, N=%d E=%d per GPU, h=%d d=%d, chunk_size=%d, "
-                               "int64 CSR both orientations" % (name, args.alpha, n_rows if world == 1 else runner.n_own,
+                               "int64 CSR both orientations" % (name, args.alpha, n_rows if runner is None else runner.n_own,
                                                                  g.n_edges, h, d, args.chunk_size),
                    "graph": name, "nodes": n_rows, "edges": total_edges, "heads": h, "d": d,
                    "chunk_size": args.chunk_size, "row_chunks": g.n_row_chunks, "col_chunks": g.n_col_chunks,
-                   "parallelism": "single GPU" if world == 1 else "node-range shards x%d, RCCL all-to-all halo" % world},
+                   "parallelism": ("single GPU" if world == 1 else "node-range shards x%d, RCCL all-to-all halo" % world)
+                                  + (" [EMULATED shard 0 of %d, no collectives]" % args.emulate_world if args.emulate_world > 1 else "")},
         "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3)},
         "roofline": roofline,
     }

@@ -1,0 +1,197 @@
+"""Node-range partitioned attention step over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Not in the reference (single process, single GPU) -- BASELINE.json's north_star
+asks for it.  Design:
+
+* Nodes are cut into `world` contiguous ranges.  Rank p owns the Q/K/V/dO rows of its range and
+  every edge whose SOURCE row is in its range (so all per-edge scalars s, a, ds, da of a row live
+  with the row's owner and the row softmax is local).
+* Columns are renumbered locally: own nodes first ([0, n_own)), then the distinct remote
+  neighbours ("halo", sorted by global id, i.e. grouped by owner).  The local graph is an
+  n_own x (n_own + n_halo) chunked CSR and runs through the unchanged single-GPU operators.
+* Forward exchange: one variable-size all_to_all delivers the halo rows of [K | V] (packed side
+  by side so one collective moves both).  Backward exchange: the partial dK/dV rows computed for
+  halo columns travel back with the transposed split sizes and are added into the owners' rows.
+  xGMI is point-to-point: all_to_all drives all 7 links of a GPU at once; no ring collective.
+* Index maps are integer and exact: re-assembling the shards reproduces the single-GPU result up
+  to fp32 summation order (tests/test_dist.py).
+
+The local operator set is injectable (`ops`): the product default is the HIP path
+(custom_op_benchmark_amd.graphop); the CPU tests pass the oracle, since the HIP path has no CPU
+implementation.
+"""
+import torch
+import torch.distributed as dist
+
+from . import graphs
+
+
+def balanced_ranges(out_degree, world):
+    """Contiguous node ranges with ~equal edge counts: boundaries[p] .. boundaries[p+1]."""
+    n = out_degree.numel()
+    cum = torch.cumsum(out_degree.to(torch.int64), 0)
+    total = int(cum[-1]) if n else 0
+    bounds = [0]
+    for p in range(1, world):
+        target = total * p // world
+        b = int(torch.searchsorted(cum, torch.tensor([target], dtype=torch.int64, device=cum.device))[0])
+        bounds.append(min(max(b, bounds[-1]), n))
+    bounds.append(n)
+    return bounds
+
+
+class ShardedAttention:
+    def __init__(self, rank, world, bounds, src_global, dst_global, device, chunk_size=32, ops=None,
+                 group=None, emulate=False):
+        """src_global/dst_global: the edges whose source lies in this rank's range (any order).
+        emulate=True builds one shard without a process group: collectives are replaced by local
+        copies of the right sizes (single-GPU rehearsal of a shard's compute, bench.py
+        --emulate-world); results are then NOT the distributed result."""
+        self.rank, self.world, self.bounds, self.group = rank, world, list(bounds), group
+        self.emulate = emulate
+        self.device = torch.device(device)
+        self.ops = ops
+        lo, hi = bounds[rank], bounds[rank + 1]
+        self.lo, self.n_own = lo, hi - lo
+        src_global = src_global.to(self.device, torch.int64)
+        dst_global = dst_global.to(self.device, torch.int64)
+        assert src_global.numel() == 0 or (int(src_global.min()) >= lo and int(src_global.max()) < hi)
+
+        own = (dst_global >= lo) & (dst_global < hi)
+        remote = dst_global[~own]
+        halo_ids = torch.unique(remote)                       # sorted global ids of halo nodes
+        self.n_halo = int(halo_ids.numel())
+        dst_local = torch.empty_like(dst_global)
+        dst_local[own] = dst_global[own] - lo
+        dst_local[~own] = self.n_own + torch.searchsorted(halo_ids, remote)
+        self.halo_ids = halo_ids
+        self.graph = graphs.graph_from_coo(src_global - lo, dst_local, self.n_own, self.n_own + self.n_halo,
+                                           chunk_size)
+
+        # who owns each halo node -> how many rows we receive from every peer (halo is owner-major)
+        b = torch.tensor(bounds, dtype=torch.int64, device=self.device)
+        owner = torch.searchsorted(b, halo_ids, right=True) - 1
+        self.recv_counts = torch.bincount(owner, minlength=world).tolist()
+        # tell every peer which of its rows we need (setup-time exchange of id lists)
+        send_counts = self._exchange_counts(self.recv_counts)
+        need_local = (halo_ids - b[owner]).contiguous()       # row index inside the owner's range
+        serve = torch.empty(sum(send_counts), dtype=torch.int64, device=self.device)
+        if emulate:   # pretend the peers ask for as many of our rows as we ask of theirs
+            serve = torch.arange(sum(send_counts), device=self.device) % max(1, self.n_own)
+        else:
+            self._all_to_all(serve, need_local, send_counts, self.recv_counts)
+        self.send_counts = send_counts
+        self.serve_rows = serve                                # our rows, grouped by destination peer
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def _exchange_counts(self, counts):
+        t_in = torch.tensor(counts, dtype=torch.int64, device=self.device)
+        t_out = torch.empty_like(t_in)
+        if self.world == 1 or self.emulate:
+            return counts
+        dist.all_to_all_single(t_out, t_in, group=self.group)
+        return t_out.tolist()
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        if self.emulate:
+            n = min(out.shape[0], inp.shape[0])
+            out[:n].copy_(inp[:n])
+            if out.shape[0] > n:
+                out[n:].zero_()
+            return
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)   # splits count rows
+
+    def gather_halo(self, X_own):
+        """Rows of X (any trailing shape) for the halo nodes, fetched from their owners."""
+        send = X_own[self.serve_rows]
+        recv = X_own.new_empty((self.n_halo,) + tuple(X_own.shape[1:]))
+        self._all_to_all(recv, send.contiguous(), self.recv_counts, self.send_counts)
+        return recv
+
+    def scatter_halo_grad(self, dX_own, dX_halo):
+        """Send partial gradient rows of halo nodes back to their owners and add them there."""
+        recv = dX_own.new_empty((int(self.serve_rows.numel()),) + tuple(dX_own.shape[1:]))
+        self._all_to_all(recv, dX_halo.contiguous(), self.send_counts, self.recv_counts)
+        dX_own.index_add_(0, self.serve_rows, recv)
+        return dX_own
+
+    # ---- the step --------------------------------------------------------------------------------
+    def _ops(self):
+        if self.ops is not None:
+            return self.ops
+        from . import graphop
+        return graphop
+
+    def step(self, Q, K, V, dO):
+        """fwd+bwd of SDDMM -> row softmax -> SpMM for this rank's rows.
+        Q, K, V, dO: (n_own, [h,] d).  Returns dict(o, dQ, dK, dV, s, a) for the own rows / edges.
+        If Q/K/V require grad their .grad is set (detached), mirroring functions.attention_step."""
+        ops, g = self._ops(), self.graph
+        Qd, Kd, Vd = Q.detach(), K.detach(), V.detach()
+        n_own = self.n_own
+        # one exchange for K and V: pack them side by side on the last dim
+        kv_halo = self.gather_halo(torch.cat([Kd, Vd], dim=-1))
+        d = Kd.shape[-1]
+        K_ext = torch.cat([Kd, kv_halo[..., :d]], 0).contiguous()
+        V_ext = torch.cat([Vd, kv_halo[..., d:]], 0).contiguous()
+        a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+        a8 = g.csr_args()
+        s = ops.maskedmm_csr_forward(*a4, Qd.contiguous(), K_ext)
+        a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+        o_ext = ops.vector_spmm_forward(*a4, a, V_ext)          # (n_ext, ...) ; rows >= n_own are 0
+        o = o_ext[:n_own]
+        # dy is only indexed by row ids (< n_own): no need to pad it to the extended row count
+        da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
+        ds = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
+        # maskedmm backward wants A and B; A = Q padded to the row count of the column CSR's ids
+        dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd.contiguous(), K_ext, ds)
+        dK = dK_ext[:n_own].clone()
+        dV = dV_ext[:n_own].clone()
+        if self.n_halo or self.world > 1:
+            packed = torch.cat([dK_ext[n_own:], dV_ext[n_own:]], dim=-1)
+            both = torch.cat([dK, dV], dim=-1)
+            self.scatter_halo_grad(both, packed)
+            dK, dV = both[..., :d].contiguous(), both[..., d:].contiguous()
+        for t, gr in ((Q, dQ), (K, dK), (V, dV)):
+            if t.requires_grad:
+                t.grad = gr
+        return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    # ---- builders --------------------------------------------------------------------------------
+    @classmethod
+    def from_global_coo(cls, src, dst, n_nodes, rank, world, device, chunk_size=32, ops=None, group=None):
+        """Every rank holds the full edge list (small graphs / tests); ranges balanced by edges."""
+        deg = torch.bincount(src.to(torch.int64), minlength=n_nodes)
+        bounds = balanced_ranges(deg, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        m = (src >= lo) & (src < hi)
+        return cls(rank, world, bounds, src[m], dst[m], device, chunk_size, ops, group)
+
+    @classmethod
+    def synthetic(cls, n_per_rank, e_per_rank, world, rank, device, alpha=0.5, seed=0, chunk_size=32,
+                  ops=None, group=None, emulate=False):
+        """Weak-scaling bench graph: `world` equal node ranges of a Chung-Lu graph with
+        world*n_per_rank nodes; each rank draws the e_per_rank edges of its own rows on its own
+        device (sources from its range, destinations from the global weight vector)."""
+        n_total = n_per_rank * world
+        w = graphs.powerlaw_weights(n_total, alpha, seed, device)
+        bounds = [p * n_per_rank for p in range(world + 1)]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        cdf_all = torch.cumsum(w, 0); cdf_all[-1] = 1.0
+        w_own = w[lo:hi] / w[lo:hi].sum()
+        cdf_own = torch.cumsum(w_own, 0); cdf_own[-1] = 1.0
+        gen = torch.Generator(device=device).manual_seed(seed + 1000 * (rank + 1))
+        srcs, dsts = [], []
+        batch = 1 << 26
+        for s0 in range(0, e_per_rank, batch):
+            m = min(batch, e_per_rank - s0)
+            u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
+            srcs.append(lo + torch.searchsorted(cdf_own, u).clamp_(max=n_per_rank - 1))
+            u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
+            dsts.append(torch.searchsorted(cdf_all, u).clamp_(max=n_total - 1))
+        return cls(rank, world, bounds, torch.cat(srcs), torch.cat(dsts), device, chunk_size, ops, group,
+                   emulate)

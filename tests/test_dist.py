@@ -1,0 +1,86 @@
+"""Multi-GPU path on CPU: world_size 2 (and 3) over gloo, local operators = the CPU oracle.
+The sharded step, re-assembled, must reproduce the single-process step on the global graph; the
+local<->global index maps must be exact."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from custom_op_benchmark_amd import graphs
+from custom_op_benchmark_amd.dist import ShardedAttention, balanced_ranges
+
+from util import oracle_step, rand_inputs, random_graph
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, h, d, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
+        inp = rand_inputs(g, h, d, seed=22, normal=True)
+        sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle)
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        # index maps: local column ids map back to the global ids exactly
+        ext_ids = torch.cat([torch.arange(lo, hi), sh.halo_ids])
+        m = (g.src >= lo) & (g.src < hi)
+        # (the local CSR orders a row's slots by LOCAL column id: own columns first, then halo)
+        key_local = (sh.graph.src + lo) * g.n_dst + ext_ids[sh.graph.dst]
+        key_global = g.src[m] * g.n_dst + g.dst[m]
+        assert torch.equal(torch.sort(key_local).values, torch.sort(key_global).values)
+        assert sum(sh.recv_counts) == sh.n_halo and sh.recv_counts[rank] == 0
+        r = sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
+        torch.save({k: v for k, v in r.items()} | {"lo": lo, "hi": hi, "edge_mask": m, "key": key_local},
+                   os.path.join(out_dir, "r%d.pt" % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,d", [(2, 1, 16), (3, 2, 8)])
+def test_sharded_step_matches_single_process(tmp_path, world, h, d):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, h, d, str(tmp_path)), nprocs=world, join=True)
+    g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
+    inp = rand_inputs(g, h, d, seed=22, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    got = {k: torch.zeros_like(want[k]) for k in ("o", "dQ", "dK", "dV", "s", "a")}
+    for r in range(world):
+        z = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        lo, hi = z["lo"], z["hi"]
+        for k in ("o", "dQ", "dK", "dV"):
+            got[k][lo:hi] = z[k]
+        # a rank's edges are the global edges of its rows; order them by (src, global dst).
+        # (duplicate edges carry identical values, so ties are harmless)
+        order = torch.argsort(z["key"], stable=True)
+        got["s"][z["edge_mask"]] = z["s"][order]
+        got["a"][z["edge_mask"]] = z["a"][order]
+    for k in got:
+        torch.testing.assert_close(got[k], want[k], rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
+
+
+def test_balanced_ranges():
+    deg = torch.tensor([0, 10, 0, 0, 5, 5, 20, 0, 0, 0])
+    b = balanced_ranges(deg, 4)
+    assert b[0] == 0 and b[-1] == 10 and all(x <= y for x, y in zip(b, b[1:]))
+    assert balanced_ranges(deg, 1) == [0, 10]
+    assert balanced_ranges(torch.zeros(5, dtype=torch.int64), 3)[-1] == 5
+
+
+def test_single_rank_has_no_halo():
+    g = graphs.uniform_random_graph(40, 400, seed=3, chunk_size=8)
+    inp = rand_inputs(g, 1, 8, seed=4)
+    sh = ShardedAttention(0, 1, [0, 40], g.src, g.dst, "cpu", chunk_size=8, ops=oracle)
+    assert sh.n_halo == 0
+    r = sh.step(inp["Q"], inp["K"], inp["V"], inp["dO"])
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    for k in ("o", "dQ", "dK", "dV"):
+        torch.testing.assert_close(r[k], want[k], rtol=1e-5, atol=1e-6)
