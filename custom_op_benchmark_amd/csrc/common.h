@@ -72,6 +72,7 @@ struct Sweep {
   int* wp_hi = nullptr;   // [W*V] one past its last slot inside window w
   int* sync = nullptr;    // [kSweepSyncInts] pacing counters (zeroed before every sweep launch)
 };
+constexpr long long kLongSegment = 512;    // rows above this many slots get a whole workgroup in softmax
 constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
 }  // namespace graphop
 
@@ -87,6 +88,8 @@ struct graphop_plan {
   int64_t* seg_chunk;      // [n_segments + 1] first chunk of each segment, then n_chunks (owned)
   int32_t* idx32;          // [n_edges] (owned, optional)
   int32_t* eid32;          // [n_edges] (owned, optional; NULL when eid is the identity)
+  int32_t* long_segs;      // [n_long] segments longer than kLongSegment slots (owned)
+  int64_t n_long;
   int device;
 };
 

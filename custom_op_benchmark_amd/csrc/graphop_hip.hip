@@ -360,14 +360,18 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
   const bool id = p->info.eid_identity != 0;
   if (pow2(h) && h <= 64) {
     const int G = seg_group_width(p->info.n_edges * h / S, h);
-    const unsigned nb = blocks_for(S, kFastBlock / G);
+    const int n_long = (int)p->n_long;
+    const unsigned nb = blocks_for(S, kFastBlock / G) + (unsigned)n_long;
+    const i64 long_len = n_long > 0 ? kLongSegment : (i64)1 << 62;
 #define GO_SEG(GW, ID)                                                                           \
   if constexpr (!BWD)                                                                            \
     hipLaunchKernelGGL((k_softmax_fwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
-                       (const i64*)p->seg_chunk, indptr, eid, in0, out, S, (int)h);              \
+                       (const i64*)p->seg_chunk, indptr, eid, in0, out, S, (int)h, long_len,     \
+                       (const int*)p->long_segs, n_long);                                        \
   else                                                                                           \
     hipLaunchKernelGGL((k_softmax_bwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
-                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, (int)h);
+                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, (int)h, long_len, \
+                       (const int*)p->long_segs, n_long);
 #define GO_SEG_ID(GW) if (id) { GO_SEG(GW, true) } else { GO_SEG(GW, false) }
     switch (G) {
       case 8: GO_SEG_ID(8) break;
@@ -577,6 +581,7 @@ void graphop_plan_destroy(graphop_plan_t* plan) {
   if (plan->seg_chunk) (void)hipFree(plan->seg_chunk);
   if (plan->idx32) (void)hipFree(plan->idx32);
   if (plan->eid32) (void)hipFree(plan->eid32);
+  if (plan->long_segs) (void)hipFree(plan->long_segs);
   free(plan);
 }
 

@@ -680,16 +680,65 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
 // the flattened (slot, head) pairs so that for eid == identity the reads are fully coalesced.
 // Requires G % h == 0 (then a lane always sees the same head t = lane % h).
 // Semantics: graphop_kernel.cu:170-202 (m starts at -1e9, :428).
+constexpr int kSoftmaxCache = 8;   // items per lane kept in registers (rows up to G*8 items: one read)
+
+template <typename T>
+__device__ __forceinline__ T neg_inf();
+template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+
+// Segments longer than `long_len` slots are left to k_softmax_*_long (one workgroup per row).
 template <typename T, int G, bool EID_ID>
-__global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
+__device__ __forceinline__ void softmax_fwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
-    const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h) {
+    const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
+    i64 long_len, i64 block) {
+  constexpr int R = kSoftmaxCache;
   const int l = threadIdx.x % G;
-  const i64 s = (i64)blockIdx.x * (kFastBlock / G) + threadIdx.x / G;
+  const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
   const i64 e0 = indptr[seg_chunk[s]];
-  const i64 items = (indptr[seg_chunk[s + 1]] - e0) * h;
+  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  if (len > long_len) return;
+  const i64 items = len * h;
   const int t = l % h;
+
+  auto offs = [&](i64 q) -> i64 {   // identity eid: (e0 + q/h)*h + q%h == e0*h + q
+    if constexpr (EID_ID) return e0 * h + q;
+    else return eid[e0 + q / h] * h + t;
+  };
+  if (items <= (i64)G * R) {   // whole row in registers: x read once, one exp per item
+    T v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i64 q = l + (i64)r * G;
+      v[r] = q < items ? x[offs(q)] : neg_inf<T>();
+    }
+    T m = (T)-1e9;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = v[r] > m ? v[r] : m;
+#pragma unroll
+    for (int mask = G / 2; mask >= 1; mask >>= 1)
+      if (mask >= h) {
+        const T m2 = __shfl_xor(m, mask, G);
+        m = m > m2 ? m : m2;
+      }
+    T sum = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[r] = (l + (i64)r * G) < items ? exp_t(v[r] - m) : (T)0;
+      sum += v[r];
+    }
+#pragma unroll
+    for (int mask = G / 2; mask >= 1; mask >>= 1)
+      if (mask >= h) sum += __shfl_xor(sum, mask, G);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i64 q = l + (i64)r * G;
+      if (q < items) y[offs(q)] = v[r] / sum;
+    }
+    return;
+  }
 
   T m = (T)-1e9, sum = 0;
   for (i64 q = l; q < items; q += G) {
@@ -721,16 +770,68 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
 
 // Backward: g = sum dy*y over the row; dx = dy*y - g*y   (graphop_kernel.cu:208-230)
 template <typename T, int G, bool EID_ID>
-__global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
+__device__ __forceinline__ void softmax_bwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
-    T* __restrict__ dx, i64 n_seg, int h) {
+    T* __restrict__ dx, i64 n_seg, int h, i64 long_len, i64 block) {
+  constexpr int R = kSoftmaxCache;
   const int l = threadIdx.x % G;
-  const i64 s = (i64)blockIdx.x * (kFastBlock / G) + threadIdx.x / G;
+  const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
   const i64 e0 = indptr[seg_chunk[s]];
-  const i64 items = (indptr[seg_chunk[s + 1]] - e0) * h;
+  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  if (len > long_len) return;
+  const i64 items = len * h;
   const int t = l % h;
+
+  auto offs = [&](i64 q) -> i64 {
+    if constexpr (EID_ID) return e0 * h + q;
+    else return eid[e0 + q / h] * h + t;
+  };
+  if (items <= (i64)G * R) {
+    T yy[R], dd[R];
+    T g = 0;
+    const int n_it = (int)items;
+    if constexpr (EID_ID) {   // one base address + immediate offsets r*G
+      const T* yp = y + e0 * h + l;
+      const T* dp = dy + e0 * h + l;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool ok = l + r * G < n_it;
+        yy[r] = ok ? yp[r * G] : (T)0;
+        dd[r] = ok ? dp[r * G] : (T)0;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const i64 q = l + (i64)r * G;
+        yy[r] = 0; dd[r] = 0;
+        if (q < items) {
+          const i64 o = offs(q);
+          yy[r] = y[o];
+          dd[r] = dy[o];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) g += dd[r] * yy[r];
+#pragma unroll
+    for (int mask = G / 2; mask >= 1; mask >>= 1)
+      if (mask >= h) g += __shfl_xor(g, mask, G);
+    if constexpr (EID_ID) {
+      T* xp = dx + e0 * h + l;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (l + r * G < n_it) xp[r * G] = dd[r] * yy[r] - g * yy[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const i64 q = l + (i64)r * G;
+        if (q < items) dx[offs(q)] = dd[r] * yy[r] - g * yy[r];
+      }
+    }
+    return;
+  }
 
   T g = 0;
   for (i64 q = l; q < items; q += G) {
@@ -747,6 +848,150 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
     const T yy = y[o];
     dx[o] = dy[o] * yy - g * yy;
   }
+}
+
+// Long rows: one 256-thread workgroup per row segment listed in long_segs[] (rows above
+// kLongSegment slots).  Up to 256*kBlockCache items are held in registers (one read of the inputs,
+// one exp per item); longer rows loop twice.  Per-head partials are merged through LDS.
+// Requires 256 % h == 0.
+constexpr int kBlockCache = 8;
+
+template <typename T, bool BWD>
+__device__ __forceinline__ void block_merge(T& m, T& sum, T* sh_m, T* sh_s, int h) {
+  const int tid = threadIdx.x;
+  __syncthreads();                       // previous users of sh_m / sh_s are done reading
+  sh_m[tid] = m; sh_s[tid] = sum;
+  __syncthreads();
+  for (int stride = kFastBlock / 2; stride >= h; stride >>= 1) {   // tid and tid+stride share a head
+    if (tid < stride) {
+      if constexpr (!BWD) {
+        const T m1 = sh_m[tid], m2 = sh_m[tid + stride];
+        const T mn = m1 > m2 ? m1 : m2;
+        sh_s[tid] = sh_s[tid] * exp_t(m1 - mn) + sh_s[tid + stride] * exp_t(m2 - mn);
+        sh_m[tid] = mn;
+      } else {
+        sh_s[tid] += sh_s[tid + stride];
+      }
+    }
+    __syncthreads();
+  }
+  m = sh_m[tid % h]; sum = sh_s[tid % h];
+}
+
+template <typename T, bool BWD, bool EID_ID>
+__device__ __forceinline__ void softmax_long_body(
+    const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk,
+    const i64* __restrict__ indptr, const i64* __restrict__ eid, const T* __restrict__ in0,
+    const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s) {
+  constexpr int RB = kBlockCache;
+  const i64 s = long_segs[blockIdx.x];
+  const i64 e0 = indptr[seg_chunk[s]];
+  const i64 items = (indptr[seg_chunk[s + 1]] - e0) * h;
+  const int tid = threadIdx.x, t = tid % h;
+  auto offs = [&](i64 q) -> i64 {   // 256 % h == 0, so q % h == t for every q of this thread
+    if constexpr (EID_ID) return e0 * h + q;
+    else return eid[e0 + q / h] * h + t;
+  };
+  if (items <= (i64)kFastBlock * RB) {
+    T v[RB], u[BWD ? RB : 1];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const i64 q = tid + (i64)r * kFastBlock;
+      v[r] = BWD ? (T)0 : neg_inf<T>();
+      if constexpr (BWD) u[r] = 0;
+      if (q < items) {
+        const i64 o = offs(q);
+        v[r] = in0[o];
+        if constexpr (BWD) u[r] = in1[o];
+      }
+    }
+    T m = (T)-1e9, sum = 0;
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) m = v[r] > m ? v[r] : m;
+      // block max per head first, so every thread exponentiates against the final maximum
+      __syncthreads();
+      sh_m[tid] = m;
+      __syncthreads();
+      for (int stride = kFastBlock / 2; stride >= h; stride >>= 1) {
+        if (tid < stride) { const T a = sh_m[tid], b2 = sh_m[tid + stride]; sh_m[tid] = a > b2 ? a : b2; }
+        __syncthreads();
+      }
+      m = sh_m[t];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const i64 q = tid + (i64)r * kFastBlock;
+        v[r] = q < items ? exp_t(v[r] - m) : (T)0;
+        sum += v[r];
+      }
+      T mm = 0;
+      block_merge<T, true>(mm, sum, sh_m, sh_s, h);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const i64 q = tid + (i64)r * kFastBlock;
+        if (q < items) out[offs(q)] = v[r] / sum;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) sum += u[r] * v[r];
+      block_merge<T, true>(m, sum, sh_m, sh_s, h);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const i64 q = tid + (i64)r * kFastBlock;
+        if (q < items) out[offs(q)] = u[r] * v[r] - sum * v[r];
+      }
+    }
+    return;
+  }
+  T m = (T)-1e9, sum = 0;
+  for (i64 q = tid; q < items; q += kFastBlock) {
+    const i64 o = offs(q);
+    if constexpr (!BWD) {
+      const T v = in0[o];
+      if (v > m) { sum = sum * exp_t(m - v) + (T)1; m = v; }
+      else sum += exp_t(v - m);
+    } else {
+      sum += in1[o] * in0[o];
+    }
+  }
+  block_merge<T, BWD>(m, sum, sh_m, sh_s, h);
+  for (i64 q = tid; q < items; q += kFastBlock) {
+    const i64 o = offs(q);
+    if constexpr (!BWD) out[o] = exp_t(in0[o] - m) / sum;
+    else { const T yy = in0[o]; out[o] = in1[o] * yy - sum * yy; }
+  }
+}
+
+// One launch: workgroups [0, n_long) take the hub rows (dispatched first, so their long serial
+// loops overlap the bulk), the rest take kFastBlock/G ordinary row segments each.
+template <typename T, int G, bool EID_ID>
+__global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
+    i64 long_len, const int* __restrict__ long_segs, int n_long) {
+  __shared__ T sh_m[kFastBlock];
+  __shared__ T sh_s[kFastBlock];
+  if ((int)blockIdx.x < n_long)
+    softmax_long_body<T, false, EID_ID>(long_segs, seg_chunk, indptr, eid, x, (const T*)nullptr, y, h,
+                                        sh_m, sh_s);
+  else
+    softmax_fwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, x, y, n_seg, h, long_len,
+                                       (i64)blockIdx.x - n_long);
+}
+
+template <typename T, int G, bool EID_ID>
+__global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
+    T* __restrict__ dx, i64 n_seg, int h, i64 long_len, const int* __restrict__ long_segs,
+    int n_long) {
+  __shared__ T sh_m[kFastBlock];
+  __shared__ T sh_s[kFastBlock];
+  if ((int)blockIdx.x < n_long)
+    softmax_long_body<T, true, EID_ID>(long_segs, seg_chunk, indptr, eid, y, dy, dx, h, sh_m, sh_s);
+  else
+    softmax_bwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, y, dy, dx, n_seg, h, long_len,
+                                       (i64)blockIdx.x - n_long);
 }
 
 // Any h (G need not be a multiple of h): heads in an outer loop, strided reads.

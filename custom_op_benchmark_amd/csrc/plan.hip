@@ -121,6 +121,20 @@ __global__ void k_plan_seg_len(const i64* __restrict__ seg_chunk, const i64* __r
   if (mx > 0) atomicMax(&st->max_seg_len, mx);
 }
 
+__global__ void k_plan_long_segs(const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+                                 i64 n_seg, i64 thresh, int* __restrict__ out, int cap,
+                                 int* __restrict__ count) {
+  i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; s < n_seg; s += stride) {
+    const i64 len = indptr[seg_chunk[s + 1]] - indptr[seg_chunk[s]];
+    if (len > thresh) {
+      const int pos = atomicAdd(count, 1);
+      if (pos < cap) out[pos] = (int)s;
+    }
+  }
+}
+
 __global__ void k_narrow(const i64* __restrict__ src, int32_t* __restrict__ dst, i64 n) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -321,6 +335,24 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
     info.max_segment_len = h.max_seg_len;
   } else {
     info.full_coverage = E == 0;
+  }
+
+  p->long_segs = nullptr;
+  p->n_long = 0;
+  if (info.row_owned && info.max_segment_len > kLongSegment && info.n_segments < 0x7fffffffLL) {
+    const int cap = (int)(E / kLongSegment + 1);
+    DevBuf d_cnt;
+    GO_HIP(hipMalloc(&d_cnt.p, sizeof(int)));
+    GO_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(int), st));
+    GO_HIP(hipMalloc((void**)&p->long_segs, sizeof(int) * (size_t)cap));
+    hipLaunchKernelGGL(k_plan_long_segs, dim3(grid_for(info.n_segments, kBlock, 4096)), dim3(kBlock),
+                       0, st, (const i64*)p->seg_chunk, indptr, info.n_segments, (i64)kLongSegment,
+                       p->long_segs, cap, (int*)d_cnt.p);
+    GO_LAUNCH_CHECK();
+    int n_long = 0;
+    GO_HIP(hipMemcpyAsync(&n_long, d_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipStreamSynchronize(st));
+    p->n_long = n_long < cap ? n_long : cap;
   }
 
   p->sorted_in_rows = 0;

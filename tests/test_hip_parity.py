@@ -353,3 +353,23 @@ def test_sweep_matches_chunk_driver_medium(dev, force_sweep):
     assert torch.equal(sw["s"], ch["s"])
     for k in ("a", "o", "dQ", "dK", "dV"):
         torch.testing.assert_close(sw[k], ch[k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("h", [1, 4])
+def test_softmax_long_rows_and_cached_rows(dev, h):
+    """Hub rows above the long-row threshold (8192 slots) take the workgroup-per-row kernel, rows
+    up to G*8 items the register-cached single pass, the rest the two-sweep loop."""
+    g = random_graph(400, 400, 30000, seed=5 + h, chunk_size=32, zero_rows=0.1, hub=20000)
+    gen = torch.Generator().manual_seed(3)
+    es = (g.n_edges,) if h == 1 else (g.n_edges, h)
+    x = torch.randn(es, generator=gen) * 3
+    ge = torch.randn(es, generator=gen)
+    for a3 in ((g.row, g.ptr_r, g.eid_r), (g.col, g.ptr_c, g.eid_c)):
+        a3d = tuple(v.to(dev) for v in a3)
+        plan = _lib.get_plan(*a3d)
+        yo = oracle.sparse_softmax_forward(*a3, x)
+        y = ops.sparse_softmax_forward(*a3d, x.to(dev))
+        close(y, yo)
+        close(ops.sparse_softmax_backward(*a3d, y, ge.to(dev)), oracle.sparse_softmax_backward(*a3, yo, ge),
+              rtol=1e-3, atol=1e-6)
+    assert _lib.get_plan(g.row.to(dev), g.ptr_r.to(dev), g.eid_r.to(dev)).info.max_segment_len > 8192  # > 256*32 items: loop path
