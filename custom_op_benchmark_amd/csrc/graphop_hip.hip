@@ -217,13 +217,16 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   const float* a = (const float*)A;
   const float* b = (const float*)B;
   float* yy = (float*)y;
+  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);   // table < 4 GiB: 32-bit byte offsets
+#define GO_K(H1, ID, O32) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, \
+                                             sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4)
   if (h == 1) {
-    if (id) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, true, true>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
-    else hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, true, false>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+    if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
+    else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
   } else {
-    if (id) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, false, true>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
-    else hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, false, false>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4);
+    if (id) GO_K(false, true, false); else GO_K(false, false, false);
   }
+#undef GO_K
   return 1;
 }
 
@@ -239,13 +242,16 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   const float* ww = (const float*)w;
   const float* x = (const float*)X;
   float* o = (float*)out;
+  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);
+#define GO_K(H1, ID, O32) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, \
+                                             sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4)
   if (h == 1) {
-    if (id) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, true, true>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
-    else hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, true, false>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+    if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
+    else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
   } else {
-    if (id) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, false, true>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
-    else hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, false, false>), grid, block, sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4);
+    if (id) GO_K(false, true, false); else GO_K(false, false, false);
   }
+#undef GO_K
   return 1;
 }
 

@@ -42,6 +42,18 @@ __device__ __forceinline__ float4 ld4(const float* base, i64 f4_index) {
   return reinterpret_cast<const float4*>(base)[f4_index];
 }
 
+// Row slice of a gathered table.  OFF32: the table is < 4 GiB, so the byte offset fits 32 bits and
+// the load uses the scalar-base + 32-bit vector-offset form (no 64-bit VALU address math).
+template <bool OFF32>
+__device__ __forceinline__ float4 ld_row(const float* base, int src, int f4_in_row, int row_f4) {
+  if constexpr (OFF32) {
+    const unsigned off = ((unsigned)src * (unsigned)row_f4 + (unsigned)f4_in_row) * 16u;
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+  } else {
+    return reinterpret_cast<const float4*>(base)[(i64)src * row_f4 + f4_in_row];
+  }
+}
+
 template <bool NT, typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
@@ -298,7 +310,7 @@ struct StripMap {   // flat slot j of the strip -> (granule k, slot e); all grou
 };
 
 // SDDMM strip: y[eid[e]*h + head] = <A_k, B[idx[e]]> ; A rows of the group's K vrows are in LDS.
-template <int L, int NV, bool H1, bool EID_ID>
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, int lo_l, int n_l,
                                             const int* __restrict__ eid32,
                                             const int* __restrict__ idx32,
@@ -310,7 +322,6 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
   m.init<L>(lo_l, n_l, l);
   if (m.total == 0) return;
   float4 a[NV];
-  int k_cur = -1;
   // prefetch batch 0
   int nk = 0, ne = -1, nsrc = 0;
   {
@@ -329,9 +340,9 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const int tt = u < nb ? u : (nb - 1);
-      const i64 src = __shfl(my_src, tt, L);
+      const int src = __shfl(my_src, tt, L);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) b[u][v] = ld4(B, src * F4 + v * L + l);
+      for (int v = 0; v < NV; ++v) b[u][v] = ld_row<OFF32>(B, src, v * L + l, (int)F4);
     }
     // ids of the next batch (issued after the row requests so they stay in flight behind them)
     ne = -1;
@@ -350,11 +361,10 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       const bool live = u < nb;
       const int tt = live ? u : (nb - 1);
       const int kt = __shfl(my_k, tt, L);
-      if (kt != k_cur) {   // group-uniform
+      // A row of this slot's vrow straight from LDS every time: no branch, so the batch stays one
+      // basic block and the 16 dot products / DPP reductions interleave
 #pragma unroll
-        for (int v = 0; v < NV; ++v) a[v] = rowsA[(kt * NV + v) * L + l];
-        k_cur = kt;
-      }
+      for (int v = 0; v < NV; ++v) a[v] = rowsA[(kt * NV + v) * L + l];
       if constexpr (H1) {
         float p = 0.f;
 #pragma unroll
@@ -393,7 +403,7 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
 
 // SpMM strip: rowsAcc[k] += sum_e w[eid[e]*h + head] * X[idx[e]] ; partial sums of the K vrows
 // live in LDS across windows, the running granule sum in registers.
-template <int L, int NV, bool H1, bool EID_ID>
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_l, int n_l,
                                            const int* __restrict__ eid32,
                                            const int* __restrict__ idx32,
@@ -442,9 +452,9 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
     for (int u = 0; u < SB; ++u) {
       const bool live = u < nb;
       const int tt = live ? u : (nb - 1);
-      const i64 src = __shfl(my_src, tt, L);
+      const int src = __shfl(my_src, tt, L);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) x[u][v] = ld4(X, src * F4 + v * L + l);
+      for (int v = 0; v < NV; ++v) x[u][v] = ld_row<OFF32>(X, src, v * L + l, (int)F4);
       if constexpr (!H1) {
         const i64 e = __shfl(my_e, tt, L);
 #pragma unroll
@@ -597,7 +607,7 @@ struct SweepOwner {
   }
 };
 
-template <int L, int NV, bool H1, bool EID_ID>
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
     int h, int d4) {
@@ -625,12 +635,12 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f
         lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
         hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
-      sddmm_strip<L, NV, H1, EID_ID>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
+      sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
     }
   }
 }
 
-template <int L, int NV, bool H1, bool EID_ID>
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f32(
     SweepView s, const float* __restrict__ wgt, const float* __restrict__ X,
     float* __restrict__ out, int h, int d4) {
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
         hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
       cnt_l += hi_l - lo_l;
-      spmm_strip<L, NV, H1, EID_ID>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
+      spmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
     }
     // pieces of one (long) row may live in several groups: merge with float atomics
     for (int k = 0; k < nv; ++k) {
