@@ -71,13 +71,13 @@ struct Tuning {
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
-    window_kb = env_int("GRAPHOP_WINDOW_KB", 2048);
+    window_kb = env_int("GRAPHOP_WINDOW_KB", 4096);
     max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
     sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 6144);
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
-    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
+    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 1);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;

@@ -430,22 +430,32 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
       }
     }
   };
-  int nk = 0, ne = 0, nsrc = 0;
-  float nw = 0.f;
-  {
-    const int j = l;
+  // Id pipeline.  Stage A (flat slot -> slot index, eid / idx loads) runs one batch ahead; when eid
+  // is not the identity the weight w[eid] is a second dependent long-latency load, so stage A runs
+  // two batches ahead and stage B (the weight) one batch ahead.
+  struct Pre { int k, e, src; float w; };
+  auto stage_a = [&](int jbase, Pre& p) {
+    const int j = jbase + l;
     int e;
-    m.locate<L>(j < m.total ? j : m.total - 1, nk, e);   // every lane takes part in the shuffles
+    m.locate<L>(j < m.total ? j : m.total - 1, p.k, e);   // every lane takes part in the shuffles
+    p.e = -1; p.src = 0; p.w = 0.f;
     if (l < SB && j < m.total) {
-      ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
-      nsrc = __builtin_nontemporal_load(idx32 + e);
-      if constexpr (H1) nw = EID_ID ? __builtin_nontemporal_load(w + ne) : w[ne];
+      p.e = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+      p.src = __builtin_nontemporal_load(idx32 + e);
+      if constexpr (H1 && EID_ID) p.w = __builtin_nontemporal_load(w + p.e);
     }
-  }
+  };
+  auto stage_b = [&](Pre& p) {
+    if constexpr (H1 && !EID_ID) p.w = p.e >= 0 ? w[p.e] : 0.f;
+  };
+  Pre p1, p2;
+  stage_a(0, p1);
+  stage_b(p1);
+  if constexpr (!EID_ID) stage_a(SB, p2);
   for (int jb = 0; jb < m.total; jb += SB) {
     const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
-    const int my_k = nk, my_e = ne, my_src = nsrc;
-    const float my_w = nw;
+    const int my_k = p1.k, my_e = p1.e, my_src = p1.src;
+    const float my_w = p1.w;
     float4 x[SB][NV];
     float wt[H1 ? 1 : SB][H1 ? 1 : NV];   // per-head weights are loads and must be issued early
 #pragma unroll
@@ -461,16 +471,13 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
         for (int v = 0; v < NV; ++v) wt[u][v] = live ? w[e * h + hv[v]] : 0.f;
       }
     }
-    nw = 0.f;
-    {
-      const int j = jb + SB + l;
-      int e;
-      m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
-      if (l < SB && j < m.total) {
-        ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
-        nsrc = __builtin_nontemporal_load(idx32 + e);
-        if constexpr (H1) nw = EID_ID ? __builtin_nontemporal_load(w + ne) : w[ne];
-      }
+    // ids of the following batches (issued after the row requests so they stay in flight behind them)
+    if constexpr (EID_ID) {
+      stage_a(jb + SB, p1);
+    } else {
+      p1 = p2;
+      stage_b(p1);
+      stage_a(jb + 2 * SB, p2);
     }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
