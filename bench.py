@@ -126,7 +126,7 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
 
     def log(msg):
@@ -139,7 +139,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GRAPHOP_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.graph == "custom" or args.nodes or args.edges:
         N, E = args.nodes, args.edges
@@ -206,10 +210,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        ee = torch.tensor([g.n_edges], device=dev, dtype=torch.int64)
+        ee = torch.tensor([g.n_edges], device=cdev, dtype=torch.int64)
         dist.all_reduce(ee)
         total_edges = int(ee.item())
     else:

@@ -90,6 +90,8 @@ class ShardedAttention:
         t_out = torch.empty_like(t_in)
         if self.world == 1 or self.emulate:
             return counts
+        if t_in.is_cuda and dist.get_backend(self.group) == "gloo":
+            t_in, t_out = t_in.cpu(), t_out.cpu()
         dist.all_to_all_single(t_out, t_in, group=self.group)
         return t_out.tolist()
 
@@ -102,6 +104,12 @@ class ShardedAttention:
             out[:n].copy_(inp[:n])
             if out.shape[0] > n:
                 out[n:].zero_()
+            return
+        if out.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
+            o, i = out.cpu(), inp.cpu()
+            dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+            out.copy_(o)
             return
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)   # splits count rows
 
