@@ -68,6 +68,7 @@ struct Tuning {
   int sweep_k;          // vrows per lane group (0 = auto)
   int vrow_t;           // vrow length cap (0 = auto from the mean row length)
   int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
+  int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -78,6 +79,7 @@ struct Tuning {
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
     sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 1);
+    sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -156,8 +158,10 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const i64 table_bytes = n_table_rows * row_bytes;
   if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
   i64 W = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
-  if (W > t.max_windows) W = t.max_windows;
-  if (W < 2) return 0;
+  // The sweep only pays while a window fits an L2 and a (row, window) granule still holds a few
+  // slots; bigger tables / sparser rows stay on the chunk drivers (HBM-bound random row gather).
+  if (W > t.max_windows || W < 2) return 0;
+  if (pi.n_edges / pi.n_segments < (i64)t.sweep_min_granule * W) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
   int T = t.vrow_t;
   if (T <= 0) {
@@ -478,7 +482,8 @@ int graphop_tune(const char* key, int value) {
       {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
-      {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift}};
+      {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
+      {"sweep_min_granule", &t.sweep_min_granule}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
