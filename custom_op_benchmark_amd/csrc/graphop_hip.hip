@@ -69,6 +69,7 @@ struct Tuning {
   int vrow_t;           // vrow length cap (0 = auto from the mean row length)
   int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
   int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
+  int sweep_prefetch;     // touch the next window at the start of every step
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -80,6 +81,7 @@ struct Tuning {
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
     sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 1);
     sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
+    sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -187,6 +189,10 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
     rounds = 1;
     blocks = ceil_div(ceil_div(vx, K), gpb) * slots;
   }
+  out->view.win_bytes = win_cols * row_bytes;
+  out->view.table_bytes = table_bytes;
+  // one 128-B line per thread of an XCD slot's workgroups must cover a window
+  out->view.prefetch = (t.sweep_prefetch && (blocks / slots) * kFastBlock * 128 >= win_cols * row_bytes) ? 1 : 0;
   out->view.xcd_slots = slots;
   out->view.vx = (int)vx;
   out->view.wp_lo = sw->wp_lo;
@@ -483,7 +489,7 @@ int graphop_tune(const char* key, int value) {
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
       {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
-      {"sweep_min_granule", &t.sweep_min_granule}};
+      {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;

@@ -523,6 +523,9 @@ struct SweepView {
   int drift;          // a workgroup may run at most `drift` windows ahead of the slowest one
   int xcd_slots;      // grid is a multiple of this; workgroup b serves XCD slot b % xcd_slots
   int vx;             // vrows per XCD slot (multiple of K)
+  i64 win_bytes;      // bytes of gathered table per window
+  i64 table_bytes;    // bytes of the gathered table
+  int prefetch;       // 1: every workgroup touches a slice of the NEXT window at the start of a step
 };
 
 // Soft pacing between the workgroups of one sweep launch, per XCD (each XCD has its own L2, so
@@ -614,6 +617,22 @@ struct SweepOwner {
   }
 };
 
+// Pull the next window into this XCD's L2 while the current one is being gathered from: the
+// workgroups of an XCD slot (b % 8) together touch one 128-B line per thread.  The value is only
+// "used" by an empty asm so the load is kept but nothing depends on it (speed only).
+__device__ __forceinline__ int sweep_prefetch(const SweepView& s, const float* table, int next_w) {
+  int v = 0;
+  if (s.prefetch && next_w < s.W) {
+    const i64 lb = blockIdx.x / s.xcd_slots;
+    const i64 off = (lb * kFastBlock + threadIdx.x) * 128;
+    const i64 base = (i64)next_w * s.win_bytes;
+    if (off < s.win_bytes && base + off < s.table_bytes)
+      v = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(table) + base + off);
+  }
+  return v;
+}
+__device__ __forceinline__ void sweep_prefetch_retire(int v) { asm volatile("; prefetched %0" ::"v"(v)); }
+
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
@@ -642,7 +661,9 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f
         lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
         hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
+      const int pf = sweep_prefetch(s, B, w + 1);
       sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
+      sweep_prefetch_retire(pf);
     }
   }
 }
@@ -678,7 +699,9 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
         hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
       }
       cnt_l += hi_l - lo_l;
+      const int pf = sweep_prefetch(s, X, w + 1);
       spmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
+      sweep_prefetch_retire(pf);
     }
     // pieces of one (long) row may live in several groups: merge with float atomics
     for (int k = 0; k < nv; ++k) {
