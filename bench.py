@@ -161,6 +161,11 @@ def main():
                                                   seed=args.seed, chunk_size=args.chunk_size, emulate=True)
         g = runner.graph
         n_rows, n_cols = g.n_src, g.n_dst
+    elif world == 1 and name == "harness":
+        # the reference author's own fixture: 512 disjoint complete digraphs of 30 nodes (wrapper.py:79-112)
+        g = graphs.block_diagonal_graph(512, 30, chunk_size=args.chunk_size, device=dev)
+        runner = None
+        n_rows, n_cols = g.n_src, g.n_dst
     elif world == 1:
         g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev)
         runner = None
