@@ -79,7 +79,7 @@ struct Tuning {
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
-    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 1);
+    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
     sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
     sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
     n_cu = 256;
@@ -203,7 +203,7 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const i64 sync_ints = 64LL * (8 + 16 * rounds * sw->W);  // kSyncStride * (kSyncXcds + 2 * xcds * steps)
   const bool paced = t.sweep_drift > 0 && sync_ints <= kSweepSyncInts;
   out->view.sync = paced ? sw->sync : nullptr;
-  out->view.drift = paced ? t.sweep_drift : 0;
+  out->view.drift = paced ? (t.sweep_drift > 3 ? 3 : t.sweep_drift) : 0;   // pacer's LDS ring holds 4 steps
   if (paced && hipMemsetAsync(sw->sync, 0, sizeof(int) * (size_t)sync_ints, st) != hipSuccess)
     return -GRAPHOP_ERR_HIP;
   out->view.V = sw->V;

@@ -548,11 +548,12 @@ struct SweepPacer {
   int* ctr;        // this XCD's (arrivals, released) pairs
   int* reg;        // this XCD's registration counter
   int drift;
-  bool active;
-  int* flag;       // LDS word: 1 = keep pacing, 0 = gave up
-  __device__ __forceinline__ SweepPacer(const SweepView& s, int* lds_flag)
+  bool active;     // per wave
+  int* lds;        // [0..3] waves of this workgroup done with step (s & 3); [4] highest released step + 1
+  static constexpr int kWaves = kFastBlock / kWave;
+  __device__ __forceinline__ SweepPacer(const SweepView& s, int* lds_words)
       : ctr(nullptr), reg(nullptr), drift(s.drift), active(s.sync != nullptr && s.drift > 0),
-        flag(lds_flag) {
+        lds(lds_words) {
     if (!active) return;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -560,37 +561,45 @@ struct SweepPacer {
     const int steps = s.rounds * s.W;
     reg = s.sync + (i64)xcc * kSyncStride;
     ctr = s.sync + (i64)kSyncStride * (kSyncXcds + 2 * (i64)xcc * steps);
-    if (threadIdx.x == 0) {
-      *flag = 1;
+    if (threadIdx.x < 5) lds[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
       __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
   }
-  // called by every thread of the workgroup after finishing `done_step` (or -1 before step 0);
-  // returns once the workgroup may start step done_step + 1
+  // Called by every lane of a wave after the wave finished `done_step` (-1 before step 0); returns
+  // once the wave may start step done_step + 1.  No workgroup barrier: each wave signals through an
+  // LDS counter (the last wave of the workgroup forwards the arrival to the XCD counter) and polls
+  // the XCD's release word only when the LDS copy of "released up to" is not enough.
   __device__ __forceinline__ void step_done_and_wait(int done_step) {
     if (!active) return;
-    __syncthreads();                       // every wave of the workgroup finished done_step
-    if (threadIdx.x == 0 && *flag) {
+    int gave_up = 0;
+    if ((threadIdx.x & 63) == 0) {
       if (done_step >= 0) {
-        int* c = ctr + (i64)done_step * 2 * kSyncStride;
-        const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1 >= n)
-          __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* slot = lds + (done_step & 3);
+        const int old = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == kWaves - 1) {            // last wave of this workgroup for done_step
+          __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          int* c = ctr + (i64)done_step * 2 * kSyncStride;
+          const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (prev + 1 >= n)
+            __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
-      const int need = done_step + 1 - drift;   // step that everybody must have finished
-      if (need >= 0) {
+      const int need = done_step + 1 - drift;   // step that every workgroup of the XCD must have finished
+      if (need >= 0 &&
+          __hip_atomic_load(lds + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= need) {
         const int* rel = ctr + ((i64)need * 2 + 1) * kSyncStride;
         int it = 0;
         while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(16);
-          if (++it > 8000) { *flag = 0; break; }   // several ms: give up pacing for good
+          if (++it > 8000) { gave_up = 1; break; }   // several ms: give up pacing for good
         }
+        if (!gave_up)
+          __hip_atomic_fetch_max(lds + 4, need + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    __syncthreads();
-    if (*flag == 0) active = false;
+    if (__shfl(gave_up, 0)) active = false;
   }
 };
 
@@ -643,8 +652,8 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
   float4* mine = lds + (i64)g_in_blk * s.K * F4;  // [K][NV][L]
-  __shared__ int pace_flag;
-  SweepPacer pacer(s, &pace_flag);
+  __shared__ int pace_words[8];
+  SweepPacer pacer(s, pace_words);
   const SweepOwner own(s, GPB, g_in_blk);
   for (int r = 0; r < s.rounds; ++r) {
     const i64 v0 = own.first_vrow(r, s.K);
@@ -654,12 +663,14 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f
 #pragma unroll
       for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
     }
+    int lo_n = 0, hi_n = 0;   // bounds of the NEXT window's granules, fetched one step ahead
+    if (l < nv) { lo_n = s.wp_lo[v0 + l]; hi_n = s.wp_hi[v0 + l]; }
     for (int w = 0; w < s.W; ++w) {
       pacer.step_done_and_wait(r * s.W + w - 1);
-      int lo_l = 0, hi_l = 0;
-      if (l < nv) {
-        lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
-        hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
+      const int lo_l = lo_n, hi_l = hi_n;
+      if (l < nv && w + 1 < s.W) {
+        lo_n = s.wp_lo[(i64)(w + 1) * s.V + v0 + l];
+        hi_n = s.wp_hi[(i64)(w + 1) * s.V + v0 + l];
       }
       const int pf = sweep_prefetch(s, B, w + 1);
       sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
@@ -681,8 +692,8 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
   int hv[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) hv[v] = H1 ? 0 : (v * L + l) / d4;
-  __shared__ int pace_flag;
-  SweepPacer pacer(s, &pace_flag);
+  __shared__ int pace_words[8];
+  SweepPacer pacer(s, pace_words);
   const SweepOwner own(s, GPB, g_in_blk);
   for (int r = 0; r < s.rounds; ++r) {
     const i64 v0 = own.first_vrow(r, s.K);
@@ -691,12 +702,14 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
 #pragma unroll
       for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt_l = 0;        // lane k: slots vrow k received over all windows
+    int lo_n = 0, hi_n = 0;
+    if (l < nv) { lo_n = s.wp_lo[v0 + l]; hi_n = s.wp_hi[v0 + l]; }
     for (int w = 0; w < s.W; ++w) {
       pacer.step_done_and_wait(r * s.W + w - 1);
-      int lo_l = 0, hi_l = 0;
-      if (l < nv) {
-        lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
-        hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
+      const int lo_l = lo_n, hi_l = hi_n;
+      if (l < nv && w + 1 < s.W) {
+        lo_n = s.wp_lo[(i64)(w + 1) * s.V + v0 + l];
+        hi_n = s.wp_hi[(i64)(w + 1) * s.V + v0 + l];
       }
       cnt_l += hi_l - lo_l;
       const int pf = sweep_prefetch(s, X, w + 1);
