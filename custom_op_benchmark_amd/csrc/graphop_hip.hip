@@ -75,7 +75,7 @@ struct Tuning {
     sweep = env_int("GRAPHOP_SWEEP", 1);
     window_kb = env_int("GRAPHOP_WINDOW_KB", 4096);
     max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
-    sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 6144);
+    sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 4608);
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
@@ -165,20 +165,23 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   if (W > t.max_windows || W < 2) return 0;
   if (pi.n_edges / pi.n_segments < (i64)t.sweep_min_granule * W) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
-  int T = t.vrow_t;
-  if (T <= 0) {
-    const i64 mean = pi.n_edges / pi.n_segments;
-    T = (int)pow2ceil(mean > 0 ? mean : 1);
-    if (T < 64) T = 64;
-    if (T > 4096) T = 4096;
-  }
-  const Sweep* sw = nullptr;
-  const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
-  if (rc != GRAPHOP_OK) return -rc;
   int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
   if (K > L) K = L;
   const int gpb = kFastBlock / L;
   const int bpc = t.sweep_bpc < 1 ? 1 : (t.sweep_bpc > kSweepBlocksPerCu ? kSweepBlocksPerCu : t.sweep_bpc);
+  int T = t.vrow_t;
+  if (T <= 0) {
+    // vrow length cap: long rows are cut so that one round of the resident grid gets a vrow per
+    // (group, K) slot -- about E / (resident groups * K) slots each -- and never below the mean row
+    const i64 resident_vrows = (i64)t.n_cu * bpc * gpb * K;
+    i64 target = pi.n_edges / (resident_vrows > 0 ? resident_vrows : 1);
+    i64 p2 = 64;
+    while (p2 * 2 <= target && p2 < 4096) p2 <<= 1;
+    T = (int)p2;
+  }
+  const Sweep* sw = nullptr;
+  const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
+  if (rc != GRAPHOP_OK) return -rc;
   // grid: a multiple of 8 workgroups; XCD slot x (= blockIdx % 8) owns vrows [x*vx, (x+1)*vx)
   i64 blocks = (i64)t.n_cu * bpc;
   blocks -= blocks % 8;

@@ -143,3 +143,24 @@ SHAPES = {
     "products": (2449029, 61859140),
     "harness": (15360, 460800),
 }
+
+
+# ---- on-disk container (next-row N4: the reference caches its index arrays in `i.pt`,
+# wrapper.py:114-116; here one file holds both chunked CSR orientations) ---------------------------
+_GRAPH_FORMAT = 1
+
+
+def save_graph(g, path):
+    """Write an AttnGraph (all index tensors, on CPU) with torch.save."""
+    payload = {"format": _GRAPH_FORMAT}
+    for k, v in g.__dict__.items():
+        payload[k] = v.cpu() if isinstance(v, torch.Tensor) else v
+    torch.save(payload, path)
+
+
+def load_graph(path, device="cpu"):
+    payload = torch.load(path, map_location="cpu")
+    if payload.pop("format", None) != _GRAPH_FORMAT:
+        raise RuntimeError("load_graph: %s is not a graph container of format %d" % (path, _GRAPH_FORMAT))
+    g = AttnGraph(**payload)
+    return g.to(device) if str(device) != "cpu" else g

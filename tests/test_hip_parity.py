@@ -320,7 +320,7 @@ def force_sweep():
     _lib.tune("max_windows", 128); _lib.tune("sweep_min_granule", 0)
     _lib.clear_plan_cache()
     yield
-    _lib.tune("sweep_min_kb", 6144); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
+    _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
     _lib.tune("sweep_bpc", 4); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
     _lib.clear_plan_cache()
 
