@@ -62,6 +62,7 @@ struct Tuning {
   int force_generic;
   int sweep;            // use the window-sweep drivers when a plan allows it
   int window_kb;        // target bytes of gathered table per window (must sit in a 4 MiB L2)
+  int mall_window_kb;   // window size for tables beyond the Infinity Cache
   int max_windows;
   int sweep_min_kb;     // tables smaller than this are L2-friendly enough for the chunk drivers
   int sweep_bpc;        // resident blocks per CU for the sweep drivers
@@ -74,6 +75,7 @@ struct Tuning {
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
     window_kb = env_int("GRAPHOP_WINDOW_KB", 4096);
+    mall_window_kb = env_int("GRAPHOP_MALL_WINDOW_KB", 32768);
     max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
     sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 4608);
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
@@ -159,7 +161,11 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const i64 row_bytes = 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
   if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
-  i64 W = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
+  // Two tiers: tables up to 128 MB are swept in L2-sized windows; bigger ones (they do not fit the
+  // 256 MiB Infinity Cache next to the streams) in 32 MB windows that stay Infinity-Cache resident,
+  // which turns HBM-rate random row gathers into Infinity-Cache-rate ones.
+  const i64 window_bytes = table_bytes > (128LL << 20) ? (i64)t.mall_window_kb * 1024 : (i64)t.window_kb * 1024;
+  i64 W = pow2ceil(ceil_div(table_bytes, window_bytes));
   // The sweep only pays while a window fits an L2 and a (row, window) granule still holds a few
   // slots; bigger tables / sparser rows stay on the chunk drivers (HBM-bound random row gather).
   if (W > t.max_windows || W < 2) return 0;
@@ -489,7 +495,7 @@ int graphop_tune(const char* key, int value) {
   Tuning& t = tuning_mut();
   struct { const char* k; int* p; } tab[] = {
       {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
-      {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"max_windows", &t.max_windows},
+      {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"mall_window_kb", &t.mall_window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
       {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
       {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch}};

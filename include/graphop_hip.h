@@ -81,7 +81,7 @@ GRAPHOP_API const char* graphop_last_error(void);
 
 /* ---- tuning knobs (also read once from the environment as GRAPHOP_<KEY>) ----------------------
  * keys: sddmm_cpg, spmm_cpg (chunks per lane group of the chunk drivers), force_generic,
- * sweep (0/1), window_kb, max_windows, sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift,
+ * sweep (0/1), window_kb, mall_window_kb, max_windows, sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift,
  * sweep_min_granule.  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
