@@ -90,6 +90,9 @@ struct graphop_plan {
   int32_t* eid32;          // [n_edges] (owned, optional; NULL when eid is the identity)
   int32_t* long_segs;      // [n_long] segments longer than kLongSegment slots (owned)
   int64_t n_long;
+  int32_t* inv32;          // [n_edges] slot holding edge id e (inverse of eid; lazily built, owned)
+  int inv_state;           // 0 = not tried, 1 = available, -1 = eid is not a permutation
+  float* scalar_scratch;   // [n_edges] per-call transposed edge scalars (lazily allocated, owned)
   int device;
 };
 

@@ -53,6 +53,7 @@ int plan_build(graphop_plan*, i64, hipStream_t);
 int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
+int plan_get_inverse(graphop_plan*, hipStream_t);
 
 namespace {
 
@@ -71,6 +72,7 @@ struct Tuning {
   int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
   int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
   int sweep_prefetch;     // touch the next window at the start of every step
+  int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -83,6 +85,7 @@ struct Tuning {
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
     sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
     sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
+    transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
     sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
     n_cu = 256;
     int dev = 0;
@@ -151,7 +154,7 @@ struct SweepLaunch {
 // Decide whether the window-sweep driver applies and fetch / build its structure.
 // Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
 inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
-                        SweepLaunch* out) {
+                        SweepLaunch* out, int force_windows = 0) {
   const Tuning& t = tuning();
   if (!t.sweep || !plan) return 0;
   const graphop_plan_info_t& pi = plan->info;
@@ -160,16 +163,16 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
   const i64 row_bytes = 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
-  if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
+  if (!force_windows && table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
   // Two tiers: tables up to 128 MB are swept in L2-sized windows; bigger ones (they do not fit the
   // 256 MiB Infinity Cache next to the streams) in 32 MB windows that stay Infinity-Cache resident,
   // which turns HBM-rate random row gathers into Infinity-Cache-rate ones.
   const i64 window_bytes = table_bytes > (128LL << 20) ? (i64)t.mall_window_kb * 1024 : (i64)t.window_kb * 1024;
-  i64 W = pow2ceil(ceil_div(table_bytes, window_bytes));
+  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, window_bytes));
   // The sweep only pays while a window fits an L2 and a (row, window) granule still holds a few
   // slots; bigger tables / sparser rows stay on the chunk drivers (HBM-bound random row gather).
   if (W > t.max_windows || W < 2) return 0;
-  if (pi.n_edges / pi.n_segments < (i64)t.sweep_min_granule * W) return 0;
+  if (!force_windows && pi.n_edges / pi.n_segments < (i64)t.sweep_min_granule * W) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
   int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
   if (K > L) K = L;
@@ -249,16 +252,49 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   return 1;
 }
 
+// Column-major pass helper: transpose the per-slot scalars w (indexed by edge id) into slot order
+// of `plan` with a paced scatter over the OTHER (row-major, identity-eid) orientation's sweep.
+// Returns 1 and sets *w_slot when done, 0 when not applicable, <0 on error.
+inline int transpose_scalars(const graphop_plan* plan, const graphop_plan* other, i64 n_other_cols,
+                             const float* w, hipStream_t st, const float** w_slot) {
+  const Tuning& t = tuning();
+  if (!t.transpose_scalars || !plan || !other || plan->info.eid_identity || !plan->eid32) return 0;
+  if (!other->info.eid_identity || other->info.n_edges != plan->info.n_edges || n_other_cols <= 0) return 0;
+  graphop_plan* p = const_cast<graphop_plan*>(plan);
+  const int rc = plan_get_inverse(p, st);
+  if (rc != GRAPHOP_OK) return -rc;
+  if (p->inv_state != 1) return 0;
+  // windows sized so that one (XCD vrow range, window) step writes ~2 MB of the slot-order array
+  i64 Ws = pow2ceil(ceil_div(plan->info.n_edges * 4, 8LL * (2 << 20)));
+  if (Ws < 2) Ws = 2;
+  if (Ws > t.max_windows) Ws = t.max_windows;
+  SweepLaunch sl;
+  const int use = choose_sweep(other, n_other_cols, 16, 1, st, &sl, (int)Ws);
+  if (use != 1) return use;
+  ProfScope prof("transpose_scalars", st);
+  hipLaunchKernelGGL(k_scatter_scalars_sweep, dim3(sl.blocks), dim3(kFastBlock), 0, st, sl.view,
+                     (const int*)p->inv32, w, p->scalar_scratch);
+  *w_slot = p->scalar_scratch;
+  return 1;
+}
+
 template <int L, int NV>
 int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w,
-                   const void* X, void* out, i64 h, int d4, hipStream_t st) {
+                   const void* X, void* out, i64 h, int d4, const graphop_plan* other,
+                   i64 n_other_cols, hipStream_t st) {
   SweepLaunch sl;
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
   if (use != 1) return use;
-  ProfScope prof(tag, st);
-  const bool id = plan->info.eid_identity != 0;
-  const dim3 grid(sl.blocks), block(kFastBlock);
+  bool id = plan->info.eid_identity != 0;
   const float* ww = (const float*)w;
+  if (!id && h == 1) {   // column-major pass: read the weights in slot order after a blocked transpose
+    const float* w_slot = nullptr;
+    const int tr = transpose_scalars(plan, other, n_other_cols, ww, st, &w_slot);
+    if (tr < 0) return tr;
+    if (tr == 1) { ww = w_slot; id = true; }
+  }
+  ProfScope prof(tag, st);
+  const dim3 grid(sl.blocks), block(kFastBlock);
   const float* x = (const float*)X;
   float* o = (float*)out;
   const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);
@@ -323,7 +359,8 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
 template <bool EDGE_X>
 int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
                 const i64* indices, const void* w, const void* X, void* out, i64 C, i64 E,
-                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
+                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st,
+                const graphop_plan* other = nullptr, i64 n_other_cols = 0) {
   if (C == 0) return GRAPHOP_OK;
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
@@ -331,7 +368,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
     const int F = (int)(h * d), d4 = (int)(d / 4);
     {
       int use = 0;
-      GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, st); });
+      GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, other, n_other_cols, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
@@ -498,7 +535,8 @@ int graphop_tune(const char* key, int value) {
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"mall_window_kb", &t.mall_window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
       {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
-      {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch}};
+      {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch},
+      {"transpose_scalars", &t.transpose_scalars}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
@@ -608,6 +646,8 @@ void graphop_plan_destroy(graphop_plan_t* plan) {
   if (plan->idx32) (void)hipFree(plan->idx32);
   if (plan->eid32) (void)hipFree(plan->eid32);
   if (plan->long_segs) (void)hipFree(plan->long_segs);
+  if (plan->inv32) (void)hipFree(plan->inv32);
+  if (plan->scalar_scratch) (void)hipFree(plan->scalar_scratch);
   free(plan);
 }
 
@@ -658,7 +698,10 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   if (n_col_chunks > 0) {
     GO_PTR(fn, col); GO_PTR(fn, indptr_c); GO_PTR(fn, eid_c); GO_PTR(fn, indices_c); GO_PTR(fn, A); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dB", dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
-                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st));
+                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st,
+                              plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr_r,
+                                                (const i64*)eid_r, (const i64*)indices_r,
+                                                n_row_chunks, n_edges) ? plan_r : nullptr, n_b));
   }
   return GRAPHOP_OK;
 }
@@ -754,7 +797,10 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     GO_PTR(fn, col); GO_PTR(fn, indptr_t); GO_PTR(fn, eid_t); GO_PTR(fn, indices_t); GO_PTR(fn, edata); GO_PTR(fn, dy);
     // kernel_1: dx = SpMM(edata, dy) over the column-major CSR, all C' chunks (:151-163)
     GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
-                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st));
+                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st,
+                              plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr,
+                                                (const i64*)eid, (const i64*)indices, n_row_chunks,
+                                                n_edges) ? plan_r : nullptr, n_x));
   }
   return GRAPHOP_OK;
 }

@@ -732,6 +732,56 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
   }
 }
 
+// Transpose per-slot scalars between the two CSR orientations: out[inv[e]] = in[e] for every
+// slot e of the ROW-major sweep (in is read in slot order = sequentially inside a granule; the
+// writes of one (XCD vrow range, column window) step land in a few MB of the column-major array
+// and are combined in that XCD's L2 before they leave).  The column-major pass then reads its
+// weights sequentially instead of gathering 4 bytes per slot.
+__global__ __launch_bounds__(kFastBlock) void k_scatter_scalars_sweep(
+    SweepView s, const int* __restrict__ inv, const float* __restrict__ in, float* __restrict__ out) {
+  constexpr int L = 16;
+  constexpr int GPB = kFastBlock / L;
+  const int l = threadIdx.x % L;
+  const int g_in_blk = threadIdx.x / L;
+  __shared__ int pace_words[8];
+  SweepPacer pacer(s, pace_words);
+  const SweepOwner own(s, GPB, g_in_blk);
+  for (int r = 0; r < s.rounds; ++r) {
+    const i64 v0 = own.first_vrow(r, s.K);
+    const int nv = own.count(v0, s.K);
+    for (int w = 0; w < s.W; ++w) {
+      pacer.step_done_and_wait(r * s.W + w - 1);
+      int lo_l = 0, n_l = 0;
+      if (l < nv) {
+        lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
+        n_l = s.wp_hi[(i64)w * s.V + v0 + l] - lo_l;
+      }
+      StripMap m;
+      m.init<L>(lo_l, n_l, l);
+      constexpr int UB = 8;   // batches in flight per group: the loads are HBM-latency bound
+      for (int jb = 0; jb < m.total; jb += UB * L) {
+        float v[UB];
+        int pos[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int j = jb + u * L + l;
+          int k, e;
+          m.locate<L>(j < m.total ? j : m.total - 1, k, e);
+          pos[u] = -1;
+          v[u] = 0.f;
+          if (j < m.total) {
+            v[u] = __builtin_nontemporal_load(in + e);
+            pos[u] = __builtin_nontemporal_load(inv + e);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (pos[u] >= 0) out[pos[u]] = v[u];
+      }
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Row-segment softmax (plan.row_owned).  Segment s = chunks [seg_chunk[s], seg_chunk[s+1]) =
 // slots [indptr[c0], indptr[c1]); all of one row.  A group of G lanes owns a segment; items are

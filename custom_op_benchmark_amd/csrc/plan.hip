@@ -135,6 +135,20 @@ __global__ void k_plan_long_segs(const i64* __restrict__ seg_chunk, const i64* _
   }
 }
 
+__global__ void k_inv_scatter(const int32_t* __restrict__ eid32, i64 n, int32_t* __restrict__ inv) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (; k < n; k += stride) inv[eid32[k]] = (int32_t)k;
+}
+__global__ void k_inv_check(const int32_t* __restrict__ eid32, const int32_t* __restrict__ inv, i64 n,
+                            int* __restrict__ bad) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  int b = 0;
+  for (; k < n; k += stride) b |= inv[eid32[k]] != (int32_t)k;
+  if (b) atomicOr(bad, 1);
+}
+
 __global__ void k_narrow(const i64* __restrict__ src, int32_t* __restrict__ dst, i64 n) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -458,6 +472,37 @@ void plan_init_sweeps(graphop_plan* p) {
   p->sweeps = new std::vector<Sweep>();
   ((std::vector<Sweep>*)p->sweeps)->reserve(16);   // pointers handed out must stay valid
   p->sweep_mu = new std::mutex();
+}
+
+// Inverse of eid (slot of every edge id) + a float scratch of n_edges values, built on first use.
+// Returns GRAPHOP_OK with p->inv_state == 1 when available, -1 when eid is not a permutation.
+int plan_get_inverse(graphop_plan* p, hipStream_t st) {
+  auto* mu = (std::mutex*)p->sweep_mu;
+  std::lock_guard<std::mutex> lk(*mu);
+  if (p->inv_state != 0) return GRAPHOP_OK;
+  const i64 E = p->info.n_edges;
+  p->inv_state = -1;
+  if (!p->eid32 || E <= 0 || E >= 0x7fffffffLL) return GRAPHOP_OK;
+  DevBuf bad;
+  GO_HIP(hipMalloc(&bad.p, sizeof(int)));
+  GO_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+  GO_HIP(hipMalloc((void**)&p->inv32, sizeof(int32_t) * (size_t)E));
+  GO_HIP(hipMemsetAsync(p->inv32, 0xff, sizeof(int32_t) * (size_t)E, st));
+  hipLaunchKernelGGL(k_inv_scatter, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st,
+                     (const int32_t*)p->eid32, E, p->inv32);
+  hipLaunchKernelGGL(k_inv_check, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st,
+                     (const int32_t*)p->eid32, (const int32_t*)p->inv32, E, (int*)bad.p);
+  GO_LAUNCH_CHECK();
+  int h_bad = 1;
+  GO_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+  if (h_bad) { (void)hipFree(p->inv32); p->inv32 = nullptr; return GRAPHOP_OK; }
+  if (hipMalloc((void**)&p->scalar_scratch, sizeof(float) * (size_t)E) != hipSuccess) {
+    (void)hipFree(p->inv32); p->inv32 = nullptr; p->scalar_scratch = nullptr;
+    return GRAPHOP_OK;
+  }
+  p->inv_state = 1;
+  return GRAPHOP_OK;
 }
 
 }  // namespace graphop

@@ -374,3 +374,20 @@ def test_softmax_long_rows_and_cached_rows(dev, h):
         close(ops.sparse_softmax_backward(*a3d, y, ge.to(dev)), oracle.sparse_softmax_backward(*a3, yo, ge),
               rtol=1e-3, atol=1e-6)
     assert _lib.get_plan(g.row.to(dev), g.ptr_r.to(dev), g.eid_r.to(dev)).info.max_segment_len > 8192  # > 256*32 items: loop path
+
+
+def test_scalar_transpose_path_matches(dev, force_sweep):
+    """Optional column-major path (off by default): per-slot scalars transposed by a paced scatter
+    before the SpMM; must give the same dB / dx as the gather path."""
+    g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=5).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
+    _lib.tune("window_kb", 256)
+    base = hip_step(g, Q, K, V, dO)
+    _lib.tune("transpose_scalars", 1)
+    try:
+        tr = hip_step(g, Q, K, V, dO)
+    finally:
+        _lib.tune("transpose_scalars", 0)
+    for k in ("dK", "dV", "dQ", "o"):
+        torch.testing.assert_close(tr[k], base[k], rtol=1e-4, atol=1e-5)
