@@ -391,3 +391,43 @@ def test_scalar_transpose_path_matches(dev, force_sweep):
         _lib.tune("transpose_scalars", 0)
     for k in ("dK", "dV", "dQ", "o"):
         torch.testing.assert_close(tr[k], base[k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_shapes_and_paths(dev, seed):
+    """Randomised battery: shape, heads, chunk size, degree profile, square / non-square, with
+    the sweep drivers forced on or off and random pacing / window knobs.  All vs the oracle."""
+    rng = np.random.RandomState(1000 + seed)
+    h = int(rng.choice([1, 1, 2, 4, 8]))
+    d = int(rng.choice([4, 8, 16, 32, 64, 128])) if h > 1 else int(rng.choice([16, 32, 64, 128, 256, 512]))
+    while h * d > 1024:
+        d //= 2
+    n_src = int(rng.randint(40, 700))
+    n_dst = n_src if rng.rand() < 0.5 else int(rng.randint(40, 700))
+    n_edges = int(rng.randint(1, 40) * n_src)
+    cs = int(rng.choice([1, 7, 32, 64]))
+    hub = int(rng.choice([0, 0, 300, 1500]))
+    forced = bool(rng.rand() < 0.6)
+    if forced:
+        _lib.tune("sweep_min_kb", 0); _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 128)
+        _lib.tune("window_kb", int(rng.choice([1, 4, 16]))); _lib.tune("vrow_t", int(rng.choice([0, 64, 256])))
+        _lib.tune("sweep_drift", int(rng.choice([0, 1, 2, 3]))); _lib.tune("sweep_bpc", int(rng.choice([1, 2, 4])))
+        _lib.tune("sweep_prefetch", int(rng.choice([0, 1]))); _lib.tune("transpose_scalars", int(rng.choice([0, 1])))
+    _lib.clear_plan_cache()
+    try:
+        g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
+                         hub=hub or None)
+        # the reference's SpMM output is zeros_like(x): x (n_dst rows) must cover the row ids
+        if g.n_dst < g.n_src:
+            g = random_graph(n_src, n_src, n_edges, seed=seed, chunk_size=cs, hub=hub or None)
+        inp = rand_inputs(g, h, d, seed=seed + 50, normal=True)
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+        got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+        for k in ("s", "a", "o", "dQ", "dK", "dV"):
+            close(got[k], want[k], rtol=2e-4, atol=2e-5)
+    finally:
+        for key, val in (("sweep_min_kb", 4608), ("sweep_min_granule", 4), ("max_windows", 128), ("window_kb", 4096),
+                         ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 4), ("sweep_prefetch", 0),
+                         ("transpose_scalars", 0)):
+            _lib.tune(key, val)
+        _lib.clear_plan_cache()
