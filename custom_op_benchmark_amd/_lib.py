@@ -12,7 +12,7 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphop_hip.so")
+LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
 ABI_VERSION = 1
 
 F32, F64 = 0, 1
