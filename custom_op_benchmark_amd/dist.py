@@ -10,9 +10,10 @@ asks for it.  Design:
 * Columns are renumbered locally: own nodes first ([0, n_own)), then the distinct remote
   neighbours ("halo", sorted by global id, i.e. grouped by owner).  The local graph is an
   n_own x (n_own + n_halo) chunked CSR and runs through the unchanged single-GPU operators.
-* Forward exchange: one variable-size all_to_all delivers the halo rows of [K | V] (packed side
-  by side so one collective moves both).  Backward exchange: the partial dK/dV rows computed for
-  halo columns travel back with the transposed split sizes and are added into the owners' rows.
+* Forward exchange: a variable-size all_to_all delivers the halo rows of K (and one more those of
+  V) straight into the tail of preallocated extended tensors -- no packing, no concatenation.
+  Backward exchange: the partial dK / dV rows computed for halo columns (a contiguous slice of the
+  operators' outputs) travel back with the transposed split sizes and are added into the owners' rows.
   xGMI is point-to-point: all_to_all drives all 7 links of a GPU at once; no ring collective.
 * Index maps are integer and exact: re-assembling the shards reproduces the single-GPU result up
   to fp32 summation order (tests/test_dist.py).
@@ -50,6 +51,7 @@ class ShardedAttention:
         --emulate-world); results are then NOT the distributed result."""
         self.rank, self.world, self.bounds, self.group = rank, world, list(bounds), group
         self.emulate = emulate
+        self._buffers = {}
         self.device = torch.device(device)
         self.ops = ops
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -113,12 +115,14 @@ class ShardedAttention:
             return
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)   # splits count rows
 
-    def gather_halo(self, X_own):
-        """Rows of X (any trailing shape) for the halo nodes, fetched from their owners."""
-        send = X_own[self.serve_rows]
-        recv = X_own.new_empty((self.n_halo,) + tuple(X_own.shape[1:]))
-        self._all_to_all(recv, send.contiguous(), self.recv_counts, self.send_counts)
-        return recv
+    def gather_halo_into(self, X_own, X_ext):
+        """X_ext[:n_own] = X_own; X_ext[n_own:] = rows of X for the halo nodes, fetched from their
+        owners straight into the tail of the (preallocated) extended tensor -- no concatenation."""
+        n_own = self.n_own
+        X_ext[:n_own].copy_(X_own)
+        send = X_own[self.serve_rows].contiguous()
+        self._all_to_all(X_ext[n_own:], send, self.recv_counts, self.send_counts)
+        return X_ext
 
     def scatter_halo_grad(self, dX_own, dX_halo):
         """Send partial gradient rows of halo nodes back to their owners and add them there."""
@@ -126,6 +130,15 @@ class ShardedAttention:
         self._all_to_all(recv, dX_halo.contiguous(), self.send_counts, self.recv_counts)
         dX_own.index_add_(0, self.serve_rows, recv)
         return dX_own
+
+    def _ext_buffer(self, name, like):
+        """Reusable (n_own + n_halo, ...) buffer keyed by role, shape tail and dtype."""
+        key = (name, tuple(like.shape[1:]), like.dtype)
+        buf = self._buffers.get(key)
+        if buf is None:
+            buf = like.new_empty((self.n_own + self.n_halo,) + tuple(like.shape[1:]))
+            self._buffers[key] = buf
+        return buf
 
     # ---- the step --------------------------------------------------------------------------------
     def _ops(self):
@@ -139,31 +152,26 @@ class ShardedAttention:
         Q, K, V, dO: (n_own, [h,] d).  Returns dict(o, dQ, dK, dV, s, a) for the own rows / edges.
         If Q/K/V require grad their .grad is set (detached), mirroring functions.attention_step."""
         ops, g = self._ops(), self.graph
-        Qd, Kd, Vd = Q.detach(), K.detach(), V.detach()
+        Qd, Kd, Vd = Q.detach().contiguous(), K.detach(), V.detach()
         n_own = self.n_own
-        # one exchange for K and V: pack them side by side on the last dim
-        kv_halo = self.gather_halo(torch.cat([Kd, Vd], dim=-1))
-        d = Kd.shape[-1]
-        K_ext = torch.cat([Kd, kv_halo[..., :d]], 0).contiguous()
-        V_ext = torch.cat([Vd, kv_halo[..., d:]], 0).contiguous()
+        # forward exchange: halo rows of K and of V land directly behind the own rows
+        K_ext = self.gather_halo_into(Kd, self._ext_buffer("K", Kd))
+        V_ext = self.gather_halo_into(Vd, self._ext_buffer("V", Vd))
         a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
         a8 = g.csr_args()
-        s = ops.maskedmm_csr_forward(*a4, Qd.contiguous(), K_ext)
+        s = ops.maskedmm_csr_forward(*a4, Qd, K_ext)
         a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
         o_ext = ops.vector_spmm_forward(*a4, a, V_ext)          # (n_ext, ...) ; rows >= n_own are 0
         o = o_ext[:n_own]
         # dy is only indexed by row ids (< n_own): no need to pad it to the extended row count
         da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
         ds = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
-        # maskedmm backward wants A and B; A = Q padded to the row count of the column CSR's ids
-        dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd.contiguous(), K_ext, ds)
-        dK = dK_ext[:n_own].clone()
-        dV = dV_ext[:n_own].clone()
+        dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd, K_ext, ds)
+        # backward exchange: partial rows computed for halo columns go home and are added there
+        dK, dV = dK_ext[:n_own], dV_ext[:n_own]                  # views: updated in place
         if self.n_halo or self.world > 1:
-            packed = torch.cat([dK_ext[n_own:], dV_ext[n_own:]], dim=-1)
-            both = torch.cat([dK, dV], dim=-1)
-            self.scatter_halo_grad(both, packed)
-            dK, dV = both[..., :d].contiguous(), both[..., d:].contiguous()
+            self.scatter_halo_grad(dK, dK_ext[n_own:])
+            self.scatter_halo_grad(dV, dV_ext[n_own:])
         for t, gr in ((Q, dQ), (K, dK), (V, dV)):
             if t.requires_grad:
                 t.grad = gr
