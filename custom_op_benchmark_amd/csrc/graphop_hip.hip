@@ -164,15 +164,20 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const i64 row_bytes = 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
   if (!force_windows && table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
-  // Two tiers: tables up to 128 MB are swept in L2-sized windows; bigger ones (they do not fit the
-  // 256 MiB Infinity Cache next to the streams) in 32 MB windows that stay Infinity-Cache resident,
-  // which turns HBM-rate random row gathers into Infinity-Cache-rate ones.
-  const i64 window_bytes = table_bytes > (128LL << 20) ? (i64)t.mall_window_kb * 1024 : (i64)t.window_kb * 1024;
-  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, window_bytes));
-  // The sweep only pays while a window fits an L2 and a (row, window) granule still holds a few
-  // slots; bigger tables / sparser rows stay on the chunk drivers (HBM-bound random row gather).
-  if (W > t.max_windows || W < 2) return 0;
-  if (!force_windows && pi.n_edges / pi.n_segments < (i64)t.sweep_min_granule * W) return 0;
+  // Two tiers.  L2-sized windows (<= 4 MB) while a (row, window) granule still holds a few slots;
+  // otherwise, for tables that do not fit the 256 MiB Infinity Cache next to the streams, 32 MB
+  // windows that stay Infinity-Cache resident (HBM-rate random row gathers become Infinity-Cache-
+  // rate ones).  Anything else stays on the chunk drivers.
+  const i64 mean_row = pi.n_edges / pi.n_segments;
+  auto windows_ok = [&](i64 w) {
+    return w >= 2 && w <= t.max_windows && mean_row >= (i64)t.sweep_min_granule * w;
+  };
+  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
+  if (!force_windows && !windows_ok(W)) {
+    W = table_bytes > (128LL << 20) ? pow2ceil(ceil_div(table_bytes, (i64)t.mall_window_kb * 1024)) : 0;
+    if (!windows_ok(W)) return 0;
+  }
+  if (W < 2 || W > t.max_windows) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
   int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
   if (K > L) K = L;
