@@ -1002,15 +1002,25 @@ __device__ __forceinline__ void softmax_long_body(
   };
   if (items <= (i64)kFastBlock * RB) {
     T v[RB], u[BWD ? RB : 1];
+    const int n_it = (int)items;
+    // identity eid: one base address per array + immediate offsets r*256 (few address registers)
+    const T* p0 = in0 + e0 * h + tid;
+    const T* p1 = BWD ? in1 + e0 * h + tid : nullptr;
+    T* po = out + e0 * h + tid;
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const i64 q = tid + (i64)r * kFastBlock;
+      const int q = tid + r * kFastBlock;
       v[r] = BWD ? (T)0 : neg_inf<T>();
       if constexpr (BWD) u[r] = 0;
-      if (q < items) {
-        const i64 o = offs(q);
-        v[r] = in0[o];
-        if constexpr (BWD) u[r] = in1[o];
+      if (q < n_it) {
+        if constexpr (EID_ID) {
+          v[r] = p0[r * kFastBlock];
+          if constexpr (BWD) u[r] = p1[r * kFastBlock];
+        } else {
+          const i64 o = offs(q);
+          v[r] = in0[o];
+          if constexpr (BWD) u[r] = in1[o];
+        }
       }
     }
     T m = (T)-1e9, sum = 0;
@@ -1028,16 +1038,18 @@ __device__ __forceinline__ void softmax_long_body(
       m = sh_m[t];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const i64 q = tid + (i64)r * kFastBlock;
-        v[r] = q < items ? exp_t(v[r] - m) : (T)0;
+        v[r] = (tid + r * kFastBlock) < n_it ? exp_t(v[r] - m) : (T)0;
         sum += v[r];
       }
       T mm = 0;
       block_merge<T, true>(mm, sum, sh_m, sh_s, h);
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const i64 q = tid + (i64)r * kFastBlock;
-        if (q < items) out[offs(q)] = v[r] / sum;
+        const int q = tid + r * kFastBlock;
+        if (q < n_it) {
+          if constexpr (EID_ID) po[r * kFastBlock] = v[r] / sum;
+          else out[offs(q)] = v[r] / sum;
+        }
       }
     } else {
 #pragma unroll
@@ -1045,8 +1057,11 @@ __device__ __forceinline__ void softmax_long_body(
       block_merge<T, true>(m, sum, sh_m, sh_s, h);
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const i64 q = tid + (i64)r * kFastBlock;
-        if (q < items) out[offs(q)] = u[r] * v[r] - sum * v[r];
+        const int q = tid + r * kFastBlock;
+        if (q < n_it) {
+          if constexpr (EID_ID) po[r * kFastBlock] = u[r] * v[r] - sum * v[r];
+          else out[offs(q)] = u[r] * v[r] - sum * v[r];
+        }
       }
     }
     return;
