@@ -598,7 +598,7 @@ struct SweepPacer {
         int it = 0;
         while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(16);
-          if (++it > 8000) { gave_up = 1; break; }   // several ms: give up pacing for good
+          if (++it > 1500) { gave_up = 1; break; }   // ~2 ms without progress: give up pacing for good
         }
         if (!gave_up)
           __hip_atomic_fetch_max(lds + 4, need + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
