@@ -406,6 +406,22 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
   return GRAPHOP_OK;
 }
 
+// node_mul_edge fast paths: d/4 lanes per edge row, H head rows of A in registers
+inline bool nme_fast_ok(int dtype, i64 h, i64 d, i64 n_edges) {
+  if (tuning().force_generic || dtype != GRAPHOP_F32 || n_edges >= 0x7fffffffLL) return false;
+  return (d == 16 || d == 32 || d == 64 || d == 128 || d == 256) && (h == 1 || h == 2 || h == 4 || h == 8);
+}
+#define GO_NME_CASE(D, LDV, HV, ...) case D * 16 + HV: { constexpr int LD = LDV, H = HV; __VA_ARGS__; } break;
+#define GO_NME_ROW(D, LDV, ...) GO_NME_CASE(D, LDV, 1, __VA_ARGS__) GO_NME_CASE(D, LDV, 2, __VA_ARGS__) \
+                                GO_NME_CASE(D, LDV, 4, __VA_ARGS__) GO_NME_CASE(D, LDV, 8, __VA_ARGS__)
+#define GO_DISPATCH_NME(d, h, ...)                                          \
+  switch ((int)(d) * 16 + (int)(h)) {                                        \
+    GO_NME_ROW(16, 4, __VA_ARGS__) GO_NME_ROW(32, 8, __VA_ARGS__)            \
+    GO_NME_ROW(64, 16, __VA_ARGS__) GO_NME_ROW(128, 32, __VA_ARGS__)         \
+    GO_NME_ROW(256, 64, __VA_ARGS__)                                         \
+    default: break;                                                          \
+  }
+
 inline bool plan_matches(const graphop_plan* p, const i64* row, const i64* indptr, const i64* eid,
                          i64 C, i64 E) {
   return p && p->row == (const int64_t*)row && p->indptr == (const int64_t*)indptr &&
@@ -817,12 +833,27 @@ int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* 
   const char* fn = "node_mul_edge_forward";
   GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
   hipStream_t st = (hipStream_t)stream;
-  (void)plan; (void)n_a;
+  (void)n_a;
   if (n_edges * h == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
-  GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
+  const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                    n_chunks, n_edges) &&
+                       plan->info.full_coverage && plan->info.eid_identity && plan->info.indptr_monotone;
+  if (!covered) GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B);
+  if (nme_fast_ok(dtype, h, d, n_edges)) {
+    ProfScope prof("node_mul_edge_fwd", st);
+    const int cpg = tuning().spmm_cpg;
+    GO_DISPATCH_NME(d, h, {
+      const unsigned nb = blocks_for(ceil_div(n_chunks, cpg), kFastBlock / LD);
+      hipLaunchKernelGGL((k_nme_fwd_f32<LD, H>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row,
+                         (const i64*)indptr, (const i64*)eid, (const float*)A, (const float*)B,
+                         (float*)y, n_chunks, cpg);
+    });
+    GO_LAUNCH_CHECK();
+    return GRAPHOP_OK;
+  }
   return launch_sddmm<true>("node_mul_edge_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                             (const i64*)eid, A, B, y, n_chunks, n_edges, n_edges, h, d, nullptr, st);
 }
@@ -835,12 +866,29 @@ int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t*
   const char* fn = "node_mul_edge_backward";
   GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
   hipStream_t st = (hipStream_t)stream;
-  (void)plan;
   const size_t es = esize(dtype);
+  const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                    n_chunks, n_edges) &&
+                       plan->info.full_coverage && plan->info.eid_identity && plan->info.indptr_monotone;
   if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
-  if (n_edges * d > 0) { GO_PTR(fn, dB); GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_edges * d), st)); }
+  if (n_edges * d > 0) {   // every edge row is written when the chunks cover all slots: skip the E*d zero-fill
+    GO_PTR(fn, dB);
+    if (!covered) GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_edges * d), st));
+  }
   if (n_chunks == 0 || h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B); GO_PTR(fn, dy);
+  if (nme_fast_ok(dtype, h, d, n_edges)) {   // both gradients in one streaming pass over B and dy
+    ProfScope prof("node_mul_edge_bwd", st);
+    const int cpg = tuning().spmm_cpg;
+    GO_DISPATCH_NME(d, h, {
+      const unsigned nb = blocks_for(ceil_div(n_chunks, cpg), kFastBlock / LD);
+      hipLaunchKernelGGL((k_nme_bwd_f32<LD, H>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row,
+                         (const i64*)indptr, (const i64*)eid, (const float*)A, (const float*)B,
+                         (const float*)dy, (float*)dA, (float*)dB, n_chunks, cpg);
+    });
+    GO_LAUNCH_CHECK();
+    return GRAPHOP_OK;
+  }
   // kernel_0 (graphop_kernel.cu:61-73): dA[row] += sum_k dy[eid[k], j/d] * B[eid[k], j%d]
   GO_TRY(launch_spmm<true>("node_mul_edge_bwd_dA", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                            (const i64*)eid, dy, B, dA, n_chunks, n_edges, n_edges, h, d, nullptr, st));

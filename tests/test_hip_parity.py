@@ -242,7 +242,9 @@ def test_torch_ops_namespace_on_gpu(dev):
 
 
 def test_node_mul_edge_vs_oracle(dev):
-    for h, d in ((1, 64), (8, 64), (2, 5)):
+    # streaming fast paths (d in 16..256, h in 1,2,4,8) and generic fallbacks (odd d, h = 3, 16)
+    for h, d in ((1, 64), (8, 64), (2, 5), (1, 16), (4, 32), (2, 128), (8, 256), (1, 256), (3, 64), (16, 16),
+                 (1, 512)):
         g = random_graph(100, 100, 3000, seed=h + d, chunk_size=32, zero_rows=0.1, hub=200)
         gen = torch.Generator().manual_seed(1)
         A = torch.rand((100, d) if h == 1 else (100, h, d), generator=gen)
