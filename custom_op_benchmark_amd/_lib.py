@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -26,7 +26,8 @@ class PlanInfo(ctypes.Structure):
                 ("max_index", _c64), ("max_segment_len", _c64), ("rows_sorted", ctypes.c_int32),
                 ("indptr_monotone", ctypes.c_int32), ("eid_identity", ctypes.c_int32),
                 ("full_coverage", ctypes.c_int32), ("row_owned", ctypes.c_int32),
-                ("has_idx32", ctypes.c_int32)]
+                ("has_idx32", ctypes.c_int32), ("dense_fill_pct", ctypes.c_int32),
+                ("n_dense_blocks", _c64)]
 
 
 class ProfileRec(ctypes.Structure):

@@ -71,9 +71,15 @@ struct Sweep {
   int* wp_lo = nullptr;   // [W*V] first slot of vrow v inside window w
   int* wp_hi = nullptr;   // [W*V] one past its last slot inside window w
   int* sync = nullptr;    // [kSweepSyncInts] pacing counters (zeroed before every sweep launch)
+  int* queues = nullptr;  // [kQueueRing][8 * 64] task-queue heads of the window-owner drivers
+  unsigned queue_next = 0;  // next ring slot (taken under the plan's sweep mutex)
 };
 constexpr long long kLongSegment = 512;    // rows above this many slots get a whole workgroup in softmax
 constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
+// Every window-owner launch takes the next of kQueueRing sets of queue heads, so launches that
+// overlap on different streams never share one (a set is reused 64 launches later).
+constexpr int kQueueRing = 64;
+constexpr int kQueueInts = 8 * 64;        // 8 heads, one 256-B line each
 }  // namespace graphop
 
 struct graphop_plan {
@@ -93,6 +99,9 @@ struct graphop_plan {
   int32_t* inv32;          // [n_edges] slot holding edge id e (inverse of eid; lazily built, owned)
   int inv_state;           // 0 = not tried, 1 = available, -1 = eid is not a permutation
   float* scalar_scratch;   // [n_edges] per-call transposed edge scalars (lazily allocated, owned)
+  int32_t* blk_seg;        // [n_dense_blocks + 1] first segment of every dense block (owned, optional)
+  int32_t* seg_e0;         // [n_segments + 1] first slot of every segment (owned, with blk_seg)
+  int32_t* seg_row;        // [n_segments] row id of every segment (owned, with blk_seg)
   int device;
 };
 

@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "kernels_fast.h"
+#include "kernels_block.h"
 #include "kernels_generic.h"
 
 namespace graphop {
@@ -49,8 +50,9 @@ struct ProfScope {  // brackets one kernel launch with two events when profiling
 
 int partition_count(const i64*, i64, i64, i64*, hipStream_t);
 int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_t);
-int plan_build(graphop_plan*, i64, hipStream_t);
+int plan_build(graphop_plan*, i64, hipStream_t, int);
 int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
+int* plan_take_queue(graphop_plan*, const Sweep*);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
@@ -72,6 +74,11 @@ struct Tuning {
   int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
   int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
   int sweep_prefetch;     // touch the next window at the start of every step
+  int dense_blocks;       // use the fp32-MFMA block-dense drivers when the plan found a cover
+  int dense_min_fill;     // ... whose 32x32 tiles hold at least this many percent edges
+  int dense_detect_min_fill;  // plan creation keeps a block cover only above this fill (percent)
+  int sweep_mode;         // 0: workgroups own vrows and walk the windows in step (paced sweep);
+                          // 1: XCDs own windows, waves pull (window, vrow tile) tasks (window-owner)
   int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
   int n_cu;
   Tuning() {
@@ -87,6 +94,10 @@ struct Tuning {
     sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
     transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
     sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
+    sweep_mode = env_int("GRAPHOP_SWEEP_MODE", 1);
+    dense_blocks = env_int("GRAPHOP_DENSE_BLOCKS", 1);
+    dense_min_fill = env_int("GRAPHOP_DENSE_MIN_FILL", 40);
+    dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -149,6 +160,7 @@ struct SweepLaunch {
   SweepView view;
   unsigned blocks;
   size_t lds_bytes;
+  bool window_owner;
 };
 
 // Decide whether the window-sweep driver applies and fetch / build its structure.
@@ -196,6 +208,33 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const Sweep* sw = nullptr;
   const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
   if (rc != GRAPHOP_OK) return -rc;
+  out->window_owner = t.sweep_mode == 1 && !force_windows;
+  if (out->window_owner) {
+    // window-owner drivers: a resident grid of waves pulling (window, vrow tile) tasks from the
+    // eight per-XCD queue heads (sync[y * 64], zeroed here)
+    const int tile = (kWave / L) * K;
+    const i64 tiles = ceil_div(sw->V, tile);
+    if (tiles * ceil_div((i64)sw->W, 8) >= 0x7fffffffLL) return 0;
+    out->view = SweepView{};
+    out->view.wp_lo = sw->wp_lo;
+    out->view.wp_hi = sw->wp_hi;
+    out->view.vr_row = sw->vr_row;
+    out->view.idx32 = plan->idx32;
+    out->view.eid32 = plan->eid32;
+    out->view.sync = plan_take_queue(const_cast<graphop_plan*>(plan), sw);
+    out->view.V = sw->V;
+    out->view.W = sw->W;
+    out->view.K = K;
+    out->view.win_bytes = win_cols * row_bytes;
+    out->view.table_bytes = table_bytes;
+    if (hipMemsetAsync(out->view.sync, 0, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
+    i64 nb = (i64)t.n_cu * bpc;
+    const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
+    if (nb > need) nb = need;
+    out->blocks = (unsigned)(nb < 1 ? 1 : nb);
+    out->lds_bytes = (size_t)gpb * K * row_bytes;
+    return 1;
+  }
   // grid: a multiple of 8 workgroups; XCD slot x (= blockIdx % 8) owns vrows [x*vx, (x+1)*vx)
   i64 blocks = (i64)t.n_cu * bpc;
   blocks -= blocks % 8;
@@ -245,8 +284,15 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   const float* b = (const float*)B;
   float* yy = (float*)y;
   const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);   // table < 4 GiB: 32-bit byte offsets
-#define GO_K(H1, ID, O32) hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, \
-                                             sl.lds_bytes, st, sl.view, a, b, yy, (int)h, d4)
+#define GO_K(H1, ID, O32)                                                                          \
+  do {                                                                                             \
+    if (sl.window_owner)                                                                           \
+      hipLaunchKernelGGL((k_sddmm_wown_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,    \
+                         sl.view, a, b, yy, (int)h, d4);                                           \
+    else                                                                                           \
+      hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,   \
+                         sl.view, a, b, yy, (int)h, d4);                                           \
+  } while (0)
   if (h == 1) {
     if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
     else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
@@ -303,14 +349,73 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   const float* x = (const float*)X;
   float* o = (float*)out;
   const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);
-#define GO_K(H1, ID, O32) hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, \
-                                             sl.lds_bytes, st, sl.view, ww, x, o, (int)h, d4)
+#define GO_K(H1, ID, O32)                                                                          \
+  do {                                                                                             \
+    if (sl.window_owner)                                                                           \
+      hipLaunchKernelGGL((k_spmm_wown_f32<L, NV, H1, ID, O32>), grid, block, 0, st, sl.view, ww,   \
+                         x, o, (int)h, d4);                                                        \
+    else                                                                                           \
+      hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,    \
+                         sl.view, ww, x, o, (int)h, d4);                                           \
+  } while (0)
   if (h == 1) {
     if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
     else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
   } else {
     if (id) GO_K(false, true, false); else GO_K(false, false, false);
   }
+#undef GO_K
+  return 1;
+}
+
+// ---- block-dense drivers (kernels_block.h) ---------------------------------------------------------
+inline bool block_ok(const graphop_plan* plan, int dtype, i64 h, i64 d, i64 n_table_rows) {
+  const Tuning& t = tuning();
+  return t.dense_blocks && !t.force_generic && dtype == GRAPHOP_F32 && plan && plan->blk_seg &&
+         plan->info.n_dense_blocks > 0 && plan->info.dense_fill_pct >= t.dense_min_fill &&
+         (plan->info.eid_identity || plan->eid32) && n_table_rows < 0x7fffffffLL &&
+         plan->info.n_dense_blocks * h < 0x7fffffffLL && h * d < 0x7fffffffLL;
+}
+inline BlockView block_view(const graphop_plan* plan) {
+  BlockView bv;
+  bv.blk_seg = plan->blk_seg; bv.seg_e0 = plan->seg_e0; bv.seg_row = plan->seg_row;
+  bv.idx32 = plan->idx32; bv.eid32 = plan->eid32; bv.nb = (int)plan->info.n_dense_blocks;
+  return bv;
+}
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Returns 1 when the block-dense SDDMM ran, 0 when it does not apply.
+inline int try_sddmm_block(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows,
+                           const void* A, const void* B, void* y, i64 h, i64 d, hipStream_t st) {
+  if (!block_ok(plan, dtype, h, d, n_table_rows) || d % 8 != 0 || !aligned16(A) || !aligned16(B)) return 0;
+  const int nw = d % 32 == 0 ? 4 : (d % 16 == 0 ? 2 : 1);
+  ProfScope prof(tag, st);
+  const dim3 grid((unsigned)(plan->info.n_dense_blocks * h)), block(kWave * nw);
+  const BlockView bv = block_view(plan);
+  if (plan->info.eid_identity)
+    hipLaunchKernelGGL((k_sddmm_block_f32<true>), grid, block, 0, st, bv, (const float*)A,
+                       (const float*)B, (float*)y, (int)h, (int)d);
+  else
+    hipLaunchKernelGGL((k_sddmm_block_f32<false>), grid, block, 0, st, bv, (const float*)A,
+                       (const float*)B, (float*)y, (int)h, (int)d);
+  return 1;
+}
+
+inline int try_spmm_block(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows,
+                          const void* w, const void* X, void* out, i64 h, i64 d, hipStream_t st) {
+  if (!block_ok(plan, dtype, h, d, n_table_rows) || d % 32 != 0 || !aligned16(X) || !aligned16(out)) return 0;
+  const int vw = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);
+  const i64 groups = d / (32 * vw);
+  const int nw = (int)(groups < 4 ? groups : 4);
+  ProfScope prof(tag, st);
+  const dim3 grid((unsigned)(plan->info.n_dense_blocks * h)), block(kWave * nw);
+  const BlockView bv = block_view(plan);
+  const bool id = plan->info.eid_identity != 0;
+#define GO_K(VW, ID) hipLaunchKernelGGL((k_spmm_block_f32<VW, ID>), grid, block, 0, st, bv, \
+                                        (const float*)w, (const float*)X, (float*)out, (int)h, (int)d)
+  if (vw == 4) { if (id) GO_K(4, true); else GO_K(4, false); }
+  else if (vw == 2) { if (id) GO_K(2, true); else GO_K(2, false); }
+  else { if (id) GO_K(1, true); else GO_K(1, false); }
 #undef GO_K
   return 1;
 }
@@ -322,6 +427,9 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
                  i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
   if (C == 0) return GRAPHOP_OK;
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
+  if constexpr (!EDGE_B) {
+    if (try_sddmm_block(tag, dtype, plan, n_src_rows, A, B, y, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+  }
   // EDGE_B (node_mul_edge): B rows are d wide, A rows h*d wide -> fast path only for h == 1
   if (fast_ok(dtype, h, d, E, n_src_rows) && (!EDGE_B || h == 1)) {
     const int cpg = tuning().sddmm_cpg;
@@ -368,6 +476,9 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
                 const graphop_plan* other = nullptr, i64 n_other_cols = 0) {
   if (C == 0) return GRAPHOP_OK;
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
+  if constexpr (!EDGE_X) {
+    if (try_spmm_block(tag, dtype, plan, n_src_rows, w, X, out, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+  }
   if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
     const int cpg = tuning().spmm_cpg;
     const int F = (int)(h * d), d4 = (int)(d / 4);
@@ -557,6 +668,8 @@ int graphop_tune(const char* key, int value) {
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
       {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
       {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch},
+      {"sweep_mode", &t.sweep_mode}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
+      {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"transpose_scalars", &t.transpose_scalars}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
@@ -645,7 +758,7 @@ int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t
   p->info.n_edges = n_edges;
   (void)hipGetDevice(&p->device);
   plan_init_sweeps(p);
-  const int rc = plan_build(p, n_index_bound, (hipStream_t)stream);
+  const int rc = plan_build(p, n_index_bound, (hipStream_t)stream, tuning().dense_detect_min_fill);
   if (rc != GRAPHOP_OK) {
     graphop_plan_destroy(p);
     return rc;
@@ -669,6 +782,9 @@ void graphop_plan_destroy(graphop_plan_t* plan) {
   if (plan->long_segs) (void)hipFree(plan->long_segs);
   if (plan->inv32) (void)hipFree(plan->inv32);
   if (plan->scalar_scratch) (void)hipFree(plan->scalar_scratch);
+  if (plan->blk_seg) (void)hipFree(plan->blk_seg);
+  if (plan->seg_e0) (void)hipFree(plan->seg_e0);
+  if (plan->seg_row) (void)hipFree(plan->seg_row);
   free(plan);
 }
 

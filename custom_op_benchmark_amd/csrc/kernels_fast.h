@@ -46,6 +46,11 @@ struct Unroll {  // neighbour rows in flight per group (16*NV*U bytes per lane)
 __device__ __forceinline__ float4 ld4(const float* base, i64 f4_index) {
   return reinterpret_cast<const float4*>(base)[f4_index];
 }
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* base, i64 f4_index) {   // streamed once: keep it out of the caches
+  const vfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(base) + f4_index);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // Row slice of a gathered table.  OFF32: the table is < 4 GiB, so the byte offset fits 32 bits and
 // the load uses the scalar-base + 32-bit vector-offset form (no 64-bit VALU address math).
@@ -197,8 +202,8 @@ __device__ __forceinline__ void spmm_range(float4 (&acc)[NV], i64 lo, i64 hi,
 }
 
 template <int L, int NV>
-__device__ __forceinline__ void atomic_flush(float* __restrict__ out, i64 row, float4 (&acc)[NV],
-                                             int l) {
+__device__ __forceinline__ void atomic_flush(float* __restrict__ out, i64 row,
+                                             const float4 (&acc)[NV], int l) {
   constexpr i64 F4 = (i64)L * NV;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -207,6 +212,33 @@ __device__ __forceinline__ void atomic_flush(float* __restrict__ out, i64 row, f
     atomicAdd(p + 1, acc[v].y);
     atomicAdd(p + 2, acc[v].z);
     atomicAdd(p + 3, acc[v].w);
+  }
+}
+
+// Same sum, but every atomic wave-instruction covers CONSECUTIVE dwords of the row (a group's L
+// lanes add L consecutive floats = whole 64-B memory-side atomic requests) instead of one dword
+// out of every 16 B: for flushes that are frequent enough to load the memory-side atomic units.
+// Group-uniform call (all L lanes of the group active).
+template <int L, int NV>
+__device__ __forceinline__ void atomic_flush_dense(float* __restrict__ out, i64 row,
+                                                   const float4 (&acc)[NV], int l) {
+  constexpr i64 F = 4LL * L * NV;
+  float* base = out + row * F;
+  if constexpr (L >= 4) {
+    const int comp = l & 3;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int src = i * (L / 4) + (l >> 2);
+        const float x = __shfl(acc[v].x, src, L), y = __shfl(acc[v].y, src, L);
+        const float z = __shfl(acc[v].z, src, L), w = __shfl(acc[v].w, src, L);
+        const float val = comp == 0 ? x : (comp == 1 ? y : (comp == 2 ? z : w));
+        atomicAdd(base + (v * 4 + i) * L + l, val);
+      }
+    }
+  } else {
+    atomic_flush<L, NV>(out, row, acc, l);
   }
 }
 
@@ -338,16 +370,34 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       nsrc = __builtin_nontemporal_load(idx32 + e);
     }
   }
+  // h == 1: the batch's 16 results are stored AFTER the next batch's rows have been requested.
+  // vmcnt retires in issue order, so a store issued ahead of those loads would have to be
+  // acknowledged (a write to HBM) before their data could be used.
+  float prev_res = 0.f;
+  int prev_e = -1;
+  const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
   for (int jb = 0; jb < m.total; jb += SB) {
     const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
-    const int my_k = nk, my_e = ne, my_src = nsrc;
+    // Owner lanes turn (vrow k, neighbour id) into byte offsets once; slots beyond nb keep valid
+    // (stale or zero) ids, so the batch needs no per-slot clamping: their rows are fetched and
+    // dotted like the others and only the final store is masked.
+    const int my_e = ne;
+    const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
+    const unsigned my_off = OFF32 ? (unsigned)nsrc * (unsigned)(F4 * 16) : (unsigned)nsrc;
     float4 b[SB][NV];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-      const int tt = u < nb ? u : (nb - 1);
-      const int src = __shfl(my_src, tt, L);
+      const unsigned o = __shfl(my_off, u, L);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) b[u][v] = ld_row<OFF32>(B, src, v * L + l, (int)F4);
+      for (int v = 0; v < NV; ++v) {
+        if constexpr (OFF32)
+          b[u][v] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(B) + o + (v * L + l) * 16);
+        else
+          b[u][v] = reinterpret_cast<const float4*>(B)[(i64)o * F4 + v * L + l];
+      }
+    }
+    if constexpr (H1) {
+      if (prev_e >= 0) __builtin_nontemporal_store(prev_res, y + prev_e);
     }
     // ids of the next batch (issued after the row requests so they stay in flight behind them)
     ne = -1;
@@ -364,20 +414,19 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const bool live = u < nb;
-      const int tt = live ? u : (nb - 1);
-      const int kt = __shfl(my_k, tt, L);
       // A row of this slot's vrow straight from LDS every time: no branch, so the batch stays one
       // basic block and the 16 dot products / DPP reductions interleave
+      const unsigned ko = __shfl(my_koff, u, L);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) a[v] = rowsA[(kt * NV + v) * L + l];
+      for (int v = 0; v < NV; ++v) a[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
       if constexpr (H1) {
-        float p = 0.f;
+        float p = dot4(a[0], b[u][0]);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) p += dot4(a[v], b[u][v]);
+        for (int v = 1; v < NV; ++v) p += dot4(a[v], b[u][v]);
         p = group_sum<L>(p);
         if (l == u) res = p;
       } else {
-        const i64 e = __shfl(my_e, tt, L);
+        const i64 e = __shfl(my_e, u, L);
         if (d4 >= L) {
           const int sph = d4 / L;
           float acc = 0.f;
@@ -401,15 +450,18 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       }
     }
     if constexpr (H1) {
-      if (l < nb) __builtin_nontemporal_store(res, y + my_e);
+      prev_res = res;
+      prev_e = l < nb ? my_e : -1;
     }
+  }
+  if constexpr (H1) {
+    if (prev_e >= 0) __builtin_nontemporal_store(prev_res, y + prev_e);
   }
 }
 
-// SpMM strip: rowsAcc[k] += sum_e w[eid[e]*h + head] * X[idx[e]] ; partial sums of the K vrows
-// live in LDS across windows, the running granule sum in registers.
-template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
-__device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_l, int n_l,
+// `sink(k, acc)` receives the finished partial sum of granule k (group-uniform call).
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32, typename Sink>
+__device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
                                            const int* __restrict__ eid32,
                                            const int* __restrict__ idx32,
                                            const float* __restrict__ w,
@@ -426,13 +478,9 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
   int k_cur = -1;
   auto spill = [&]() {
     if (k_cur >= 0) {
+      sink(k_cur, acc);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float4 o = rowsAcc[(k_cur * NV + v) * L + l];
-        o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
-        rowsAcc[(k_cur * NV + v) * L + l] = o;
-        acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   // Id pipeline.  Stage A (flat slot -> slot index, eid / idx loads) runs one batch ahead; when eid
@@ -444,10 +492,14 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
     int e;
     m.locate<L>(j < m.total ? j : m.total - 1, p.k, e);   // every lane takes part in the shuffles
     p.e = -1; p.src = 0; p.w = 0.f;
-    if (l < SB && j < m.total) {
-      p.e = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+    if (l < SB) {
+      // slots past the end re-read the strip's last neighbour id with weight 0 (a row that is in
+      // the sum anyway), so the batch loop needs no per-slot clamping
       p.src = __builtin_nontemporal_load(idx32 + e);
-      if constexpr (H1 && EID_ID) p.w = __builtin_nontemporal_load(w + p.e);
+      if (j < m.total) {
+        p.e = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
+        if constexpr (H1 && EID_ID) p.w = __builtin_nontemporal_load(w + p.e);
+      }
     }
   };
   auto stage_b = [&](Pre& p) {
@@ -459,21 +511,25 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
   if constexpr (!EID_ID) stage_a(SB, p2);
   for (int jb = 0; jb < m.total; jb += SB) {
     const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
-    const int my_k = p1.k, my_e = p1.e, my_src = p1.src;
+    const int my_k = p1.k, my_e = p1.e;
+    const unsigned my_off = OFF32 ? (unsigned)p1.src * (unsigned)(F4 * 16) : (unsigned)p1.src;
     const float my_w = p1.w;
     float4 x[SB][NV];
     float wt[H1 ? 1 : SB][H1 ? 1 : NV];   // per-head weights are loads and must be issued early
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-      const bool live = u < nb;
-      const int tt = live ? u : (nb - 1);
-      const int src = __shfl(my_src, tt, L);
+      const unsigned o = __shfl(my_off, u, L);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) x[u][v] = ld_row<OFF32>(X, src, v * L + l, (int)F4);
+      for (int v = 0; v < NV; ++v) {
+        if constexpr (OFF32)
+          x[u][v] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + o + (v * L + l) * 16);
+        else
+          x[u][v] = reinterpret_cast<const float4*>(X)[(i64)o * F4 + v * L + l];
+      }
       if constexpr (!H1) {
-        const i64 e = __shfl(my_e, tt, L);
+        const i64 e = __shfl(my_e, u, L);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) wt[u][v] = live ? w[e * h + hv[v]] : 0.f;
+        for (int v = 0; v < NV; ++v) wt[u][v] = u < nb ? w[e * h + hv[v]] : 0.f;
       }
     }
     // ids of the following batches (issued after the row requests so they stay in flight behind them)
@@ -486,17 +542,13 @@ __device__ __forceinline__ void spmm_strip(float4* __restrict__ rowsAcc, int lo_
     }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-      const int tt = u < nb ? u : (nb - 1);
-      const int kt = __shfl(my_k, tt, L);
+      const int kt = __shfl(my_k, u, L);
       if (kt != k_cur) {   // group-uniform
         spill();
         k_cur = kt;
       }
       float w1 = 0.f;
-      if constexpr (H1) {
-        w1 = __shfl(my_w, tt, L);
-        if (u >= nb) w1 = 0.f;
-      }
+      if constexpr (H1) w1 = __shfl(my_w, u, L);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const float ww = H1 ? w1 : wt[H1 ? 0 : u][H1 ? 0 : v];
@@ -718,7 +770,15 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
       }
       cnt_l += hi_l - lo_l;
       const int pf = sweep_prefetch(s, X, w + 1);
-      spmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
+      auto to_lds = [&](int k, const float4 (&acc)[NV]) {   // partial sums of the K vrows live in LDS
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          float4 o = mine[(k * NV + v) * L + l];
+          o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+          mine[(k * NV + v) * L + l] = o;
+        }
+      };
+      spmm_strip<L, NV, H1, EID_ID, OFF32>(to_lds, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
       sweep_prefetch_retire(pf);
     }
     // pieces of one (long) row may live in several groups: merge with float atomics
@@ -729,6 +789,119 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f3
       for (int v = 0; v < NV; ++v) acc[v] = mine[(k * NV + v) * L + l];
       atomic_flush<L, NV>(out, s.vr_row[v0 + k], acc, l);
     }
+  }
+}
+
+// ---- WINDOW-OWNER drivers (plan) -----------------------------------------------------------------
+// The loop interchange of the sweep above: instead of workgroups owning vrows and all of them
+// walking the windows together (every XCD's L2 sees every window once per round, kept in step by
+// the pacer), every XCD owns the windows w = x, x+8, ... and its waves pull (window, vrow-tile)
+// tasks from that XCD's queue, window-major.  A window is then brought into exactly one L2, once,
+// and stays there for as long as that XCD works on it; nothing has to be paced.  A task is one
+// wave = 64/L lane groups x K consecutive vrows in one window.  The price: the rows' own operand
+// (SDDMM: A rows) is re-read and the partial sums (SpMM) are flushed once per (vrow, window)
+// instead of once per vrow.  An XCD whose queue is empty steals from the other queues (those tasks
+// gather through the Infinity Cache; it only matters for the tail).
+// Queue heads: SweepView::sync[y * kSyncStride], y < 8, zero at launch.
+struct WownQueue {
+  int* q;
+  int ntasks, W, x, s;
+  __device__ __forceinline__ WownQueue(const SweepView& sv, int tiles) : q(sv.sync), ntasks(tiles), W(sv.W), s(0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    x = (int)(xcc & (kSyncXcds - 1));
+  }
+  // wave-uniform; every lane calls.  Returns false when all eight queues are drained.
+  __device__ __forceinline__ bool pull(int& w, int& t) {
+    while (s < kSyncXcds) {
+      const int y = (x + s) & (kSyncXcds - 1);
+      const int nwin = (W - y + kSyncXcds - 1) / kSyncXcds;   // windows y, y+8, ... < W
+      if (nwin > 0) {
+        int idx = 0;
+        if ((threadIdx.x & (kWave - 1)) == 0)
+          idx = __hip_atomic_fetch_add(q + (i64)y * kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __shfl(idx, 0);
+        if (idx < nwin * ntasks) {
+          w = y + kSyncXcds * (idx / ntasks);
+          t = idx % ntasks;
+          return true;
+        }
+      }
+      ++s;
+    }
+    return false;
+  }
+};
+
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
+__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f32(
+    SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
+    int h, int d4) {
+  extern __shared__ float4 lds[];
+  constexpr i64 F4 = (i64)L * NV;
+  constexpr int GW = kWave / L;                // lane groups per wave
+  const int l = threadIdx.x % L;
+  const int g_in_blk = threadIdx.x / L;
+  const int g_in_wave = g_in_blk % GW;
+  float4* mine = lds + (i64)g_in_blk * s.K * F4;  // [K][NV][L]
+  const int tile = GW * s.K;
+  WownQueue queue(s, (s.V + tile - 1) / tile);
+  int w, t;
+  bool more = queue.pull(w, t);
+  while (more) {
+    const i64 v0 = (i64)t * tile + (i64)g_in_wave * s.K;
+    const int nv = v0 >= s.V ? 0 : ((s.V - v0) < s.K ? (int)(s.V - v0) : s.K);
+    int lo_l = 0, hi_l = 0, row_l = 0;
+    if (l < nv) {
+      lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
+      hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
+      row_l = s.vr_row[v0 + l];
+    }
+    int wn, tn;
+    more = queue.pull(wn, tn);    // next task id: its latency hides behind this task's strip
+    for (int k = 0; k < nv; ++k) {
+      const i64 row = __shfl(row_l, k, L);
+      if (__shfl(hi_l - lo_l, k, L) == 0) continue;   // group-uniform
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        mine[(k * NV + v) * L + l] = ld4_nt(A, row * F4 + v * L + l);
+    }
+    sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
+    w = wn; t = tn;
+  }
+}
+
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
+__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_wown_f32(
+    SweepView s, const float* __restrict__ wgt, const float* __restrict__ X,
+    float* __restrict__ out, int h, int d4) {
+  constexpr int GW = kWave / L;
+  const int l = threadIdx.x % L;
+  const int g_in_wave = (threadIdx.x % kWave) / L;
+  int hv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) hv[v] = H1 ? 0 : (v * L + l) / d4;
+  const int tile = GW * s.K;
+  WownQueue queue(s, (s.V + tile - 1) / tile);
+  int w, t;
+  bool more = queue.pull(w, t);
+  while (more) {
+    const i64 v0 = (i64)t * tile + (i64)g_in_wave * s.K;
+    const int nv = v0 >= s.V ? 0 : ((s.V - v0) < s.K ? (int)(s.V - v0) : s.K);
+    int lo_l = 0, hi_l = 0, row_l = 0;
+    if (l < nv) {
+      lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
+      hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
+      row_l = s.vr_row[v0 + l];
+    }
+    int wn, tn;
+    more = queue.pull(wn, tn);
+    // a granule's sum goes straight to the output row: one dense atomic flush per (vrow, window)
+    auto to_out = [&](int k, const float4 (&acc)[NV]) {
+      atomic_flush_dense<L, NV>(out, __shfl(row_l, k, L), acc, l);
+    };
+    spmm_strip<L, NV, H1, EID_ID, OFF32>(to_out, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
+    w = wn; t = tn;
   }
 }
 

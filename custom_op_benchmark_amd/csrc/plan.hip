@@ -234,6 +234,37 @@ __global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restri
   }
 }
 
+// ---- block-dense cover -----------------------------------------------------------------------------
+// same[s] = 1 when segment s has the same neighbour list (length and ids, in order) as segment
+// s - 1; also fills the 32-bit segment tables the block kernels read.
+__global__ void k_blk_same(const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+                           const i64* __restrict__ row, const int32_t* __restrict__ idx32, i64 S,
+                           unsigned char* __restrict__ same, int32_t* __restrict__ seg_e0,
+                           int32_t* __restrict__ seg_row, unsigned long long* __restrict__ n_same) {
+  i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  unsigned long long cnt = 0;
+  for (; s <= S; s += stride) {
+    const i64 e0 = indptr[seg_chunk[s]];
+    seg_e0[s] = (int32_t)e0;
+    if (s == S) break;
+    seg_row[s] = (int32_t)row[seg_chunk[s]];
+    unsigned char eq = 0;
+    if (s > 0) {
+      const i64 len = indptr[seg_chunk[s + 1]] - e0;
+      const i64 p0 = indptr[seg_chunk[s - 1]];
+      if (e0 - p0 == len) {
+        eq = 1;
+        for (i64 j = 0; j < len; ++j)
+          if (idx32[e0 + j] != idx32[p0 + j]) { eq = 0; break; }
+      }
+    }
+    same[s] = eq;
+    cnt += eq;
+  }
+  if (cnt) atomicAdd(n_same, cnt);
+}
+
 struct DevBuf {  // frees on scope exit (setup path only)
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -262,7 +293,9 @@ int partition_fill(const i64* indptr, const i64* first, i64 n_rows, i64 chunk, i
   return GRAPHOP_OK;
 }
 
-int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
+int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill);
+
+int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_detect_min_fill) {
   const i64 C = p->info.n_chunks, E = p->info.n_edges;
   const i64* row = (const i64*)p->row;
   const i64* indptr = (const i64*)p->indptr;
@@ -397,6 +430,70 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st) {
     GO_HIP(hipStreamSynchronize(st));
     info.has_idx32 = 1;
   }
+  return plan_detect_blocks(p, st, dense_detect_min_fill);
+}
+
+// Cover the segments with blocks of <= 32 consecutive segments that share one neighbour list of
+// <= 32 ids; keep the cover when the 32x32 tiles are filled well enough for the MFMA drivers
+// (kernels_block.h) to beat one row gather per edge.
+int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
+  graphop_plan_info_t& info = p->info;
+  info.n_dense_blocks = 0;
+  info.dense_fill_pct = 0;
+  const i64 S = info.n_segments, E = info.n_edges;
+  if (min_fill < 1) min_fill = 1;   // percent of a 32x32 tile; covers below this are not kept
+  if (!info.row_owned || !p->idx32 || S <= 0 || E <= 0 || E >= 0x7fffffffLL || S >= 0x7fffffffLL ||
+      info.max_segment_len > 32 || info.max_row >= 0x7fffffffLL)
+    return GRAPHOP_OK;
+  DevBuf same, cnt;
+  int32_t *seg_e0 = nullptr, *seg_row = nullptr;
+  GO_HIP(hipMalloc(&same.p, (size_t)S));
+  GO_HIP(hipMalloc(&cnt.p, sizeof(unsigned long long)));
+  GO_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), st));
+  if (hipMalloc((void**)&seg_e0, sizeof(int32_t) * (size_t)(S + 1)) != hipSuccess ||
+      hipMalloc((void**)&seg_row, sizeof(int32_t) * (size_t)S) != hipSuccess) {
+    (void)hipFree(seg_e0); (void)hipFree(seg_row);
+    return GRAPHOP_OK;   // optional structure: carry on without it
+  }
+  hipLaunchKernelGGL(k_blk_same, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
+                     (const i64*)p->seg_chunk, (const i64*)p->indptr, (const i64*)p->row,
+                     (const int32_t*)p->idx32, S, (unsigned char*)same.p, seg_e0, seg_row,
+                     (unsigned long long*)cnt.p);
+  unsigned long long n_same = 0;
+  bool keep = hipGetLastError() == hipSuccess &&
+              hipMemcpyAsync(&n_same, cnt.p, sizeof(n_same), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
+  // every segment that differs from its predecessor opens a block: an upper bound on the fill
+  if (keep && (double)E / (1024.0 * (double)(S - (i64)n_same)) * 100.0 < min_fill) keep = false;
+  std::vector<int32_t> blk;
+  if (keep) {
+    std::vector<unsigned char> h_same((size_t)S);
+    keep = hipMemcpy(h_same.data(), same.p, (size_t)S, hipMemcpyDeviceToHost) == hipSuccess;
+    if (keep) {
+      int run = 0;
+      for (i64 s = 0; s < S; ++s) {
+        if (s == 0 || !h_same[(size_t)s] || run == 32) { blk.push_back((int32_t)s); run = 0; }
+        ++run;
+      }
+      blk.push_back((int32_t)S);
+      const double fill = (double)E / (1024.0 * (double)(blk.size() - 1)) * 100.0;
+      if (fill < min_fill) keep = false;
+      else info.dense_fill_pct = (int32_t)(fill + 0.5) > 0 ? (int32_t)(fill + 0.5) : 1;
+    }
+  }
+  if (keep) {
+    keep = hipMalloc((void**)&p->blk_seg, sizeof(int32_t) * blk.size()) == hipSuccess &&
+           hipMemcpy(p->blk_seg, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!keep) {
+    (void)hipFree(seg_e0); (void)hipFree(seg_row);
+    if (p->blk_seg) { (void)hipFree(p->blk_seg); p->blk_seg = nullptr; }
+    info.dense_fill_pct = 0;
+    return GRAPHOP_OK;
+  }
+  p->seg_e0 = seg_e0;
+  p->seg_row = seg_row;
+  info.n_dense_blocks = (i64)blk.size() - 1;
   return GRAPHOP_OK;
 }
 
@@ -441,8 +538,10 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   if (hipMalloc((void**)&s.vr_row, sizeof(int) * (size_t)V) != hipSuccess ||
       hipMalloc((void**)&s.wp_lo, wp_bytes) != hipSuccess ||
       hipMalloc((void**)&s.wp_hi, wp_bytes) != hipSuccess ||
-      hipMalloc((void**)&s.sync, sizeof(int) * kSweepSyncInts) != hipSuccess) {
+      hipMalloc((void**)&s.sync, sizeof(int) * kSweepSyncInts) != hipSuccess ||
+      hipMalloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts) != hipSuccess) {
     (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
+    (void)hipFree(s.queues);
     set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
     return GRAPHOP_ERR_HIP;
   }
@@ -456,11 +555,18 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   return GRAPHOP_OK;
 }
 
+int* plan_take_queue(graphop_plan* p, const Sweep* sw) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  Sweep* s = const_cast<Sweep*>(sw);
+  return s->queues + (size_t)(s->queue_next++ % kQueueRing) * kQueueInts;
+}
+
 void plan_free_sweeps(graphop_plan* p) {
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
     for (auto& s : *vec) {
       (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
+      (void)hipFree(s.queues);
     }
     delete vec;
   }

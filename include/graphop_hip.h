@@ -48,7 +48,7 @@ extern "C" {
 #define GRAPHOP_API
 #endif
 
-#define GRAPHOP_ABI_VERSION 1
+#define GRAPHOP_ABI_VERSION 2
 
 #define GRAPHOP_F32 0
 #define GRAPHOP_F64 1
@@ -74,6 +74,8 @@ typedef struct graphop_plan_info {
   int32_t full_coverage;   /* indptr[0] == 0 && indptr[n_chunks] == n_edges                  */
   int32_t row_owned;       /* rows_sorted && indptr_monotone: fast paths enabled             */
   int32_t has_idx32;       /* 32-bit mirrors of eid / indices are cached                     */
+  int32_t dense_fill_pct;  /* edges per 32x32 tile of the block-dense cover, in %; 0 = no cover */
+  int64_t n_dense_blocks;  /* blocks (<= 32 consecutive rows sharing one list of <= 32 ids)   */
 } graphop_plan_info_t;
 
 GRAPHOP_API int graphop_abi_version(void);
@@ -81,8 +83,11 @@ GRAPHOP_API const char* graphop_last_error(void);
 
 /* ---- tuning knobs (also read once from the environment as GRAPHOP_<KEY>) ----------------------
  * keys: sddmm_cpg, spmm_cpg (chunks per lane group of the chunk drivers), force_generic,
- * sweep (0/1), window_kb, mall_window_kb, max_windows, sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift,
- * sweep_min_granule.  Not
+ * sweep (0/1), sweep_mode (1 = XCDs own column windows and waves pull (window, row tile) tasks;
+ * 0 = workgroups own rows and walk the windows in step), window_kb, mall_window_kb, max_windows,
+ * sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift, sweep_min_granule, sweep_prefetch,
+ * transpose_scalars, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
+ * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile).  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
 

@@ -324,13 +324,18 @@ def force_sweep():
     yield
     _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
     _lib.tune("sweep_bpc", 4); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
+    _lib.tune("sweep_mode", 1)
     _lib.clear_plan_cache()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("h,d", [(1, 64), (1, 16), (1, 256), (1, 1024), (8, 16), (8, 64), (2, 32)])
-def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d):
-    """Column-window sweep (plan path): rows longer than vrow_t are cut into pieces merged by
-    atomics, empty rows and empty windows occur, several rounds per group (tiny grid)."""
+def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d, mode):
+    """Column-window drivers (plan path), both loop orders (mode 0: workgroups own vrows and walk
+    the windows in step; mode 1: XCDs own windows, waves pull tasks): rows longer than vrow_t are
+    cut into pieces merged by atomics, empty rows and empty windows occur, several rounds per
+    group (tiny grid)."""
+    _lib.tune("sweep_mode", mode)
     _lib.tune("sweep_bpc", 1 if h * d <= 64 else 4)
     n = 120 if h * d >= 512 else 1500
     g = random_graph(n, n + 41, 10 * n, seed=h * 77 + d, chunk_size=32, zero_rows=0.15, hub=900)
@@ -341,8 +346,10 @@ def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d):
         close(got[k], want[k])
 
 
-def test_sweep_matches_chunk_driver_medium(dev, force_sweep):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
     """Same inputs through both drivers: SDDMM bit-identical, SpMM within fp32 re-association."""
+    _lib.tune("sweep_mode", mode)
     g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
     gen = torch.Generator(device=dev).manual_seed(2)
     Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
@@ -415,6 +422,7 @@ def test_fuzz_shapes_and_paths(dev, seed):
         _lib.tune("window_kb", int(rng.choice([1, 4, 16]))); _lib.tune("vrow_t", int(rng.choice([0, 64, 256])))
         _lib.tune("sweep_drift", int(rng.choice([0, 1, 2, 3]))); _lib.tune("sweep_bpc", int(rng.choice([1, 2, 4])))
         _lib.tune("sweep_prefetch", int(rng.choice([0, 1]))); _lib.tune("transpose_scalars", int(rng.choice([0, 1])))
+        _lib.tune("sweep_mode", int(rng.choice([0, 1])))
     _lib.clear_plan_cache()
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
@@ -430,6 +438,79 @@ def test_fuzz_shapes_and_paths(dev, seed):
     finally:
         for key, val in (("sweep_min_kb", 4608), ("sweep_min_granule", 4), ("max_windows", 128), ("window_kb", 4096),
                          ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 4), ("sweep_prefetch", 0),
-                         ("transpose_scalars", 0)):
+                         ("transpose_scalars", 0), ("sweep_mode", 1)):
             _lib.tune(key, val)
         _lib.clear_plan_cache()
+
+
+# ---- block-dense (fp32 MFMA) drivers -------------------------------------------------------------
+def _plans(g):
+    return (_lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r), _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c))
+
+
+@pytest.mark.parametrize("l,h,d", [(30, 1, 1024), (30, 8, 64), (32, 1, 128), (17, 2, 32), (5, 1, 8), (30, 4, 24),
+                                   (9, 1, 16)])
+def test_block_dense_drivers_vs_oracle(dev, l, h, d):
+    """Disjoint complete digraphs (the harness fixture shape, wrapper.py:79-112): the plan finds one
+    block per component in BOTH orientations and the MFMA drivers serve all six gather passes
+    (d % 32 == 0) or the three SDDMM-shaped ones (d % 8 == 0); same results with them switched off."""
+    bs = 7
+    g = graphs.block_diagonal_graph(bs, l, chunk_size=32)
+    inp = rand_inputs(g, h, d, seed=l + d, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    _lib.clear_plan_cache()
+    _lib.tune("dense_detect_min_fill", 1); _lib.tune("dense_min_fill", 1)   # small blocks too
+    try:
+        for p in _plans(gd):
+            assert p.info.n_dense_blocks == bs and p.info.dense_fill_pct == max(1, round(100 * l * l / 1024))
+        args = tuple(inp[k].to(dev) for k in ("Q", "K", "V", "dO"))
+        got = hip_step(gd, *args)
+        for k in ("s", "a", "o", "dQ", "dK", "dV"):
+            close(got[k], want[k])
+        _lib.tune("dense_blocks", 0)
+        ref = hip_step(gd, *args)
+    finally:
+        _lib.tune("dense_blocks", 1); _lib.tune("dense_detect_min_fill", 10); _lib.tune("dense_min_fill", 40)
+        _lib.clear_plan_cache()
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        torch.testing.assert_close(got[k], ref[k], rtol=1e-4, atol=1e-5)
+
+
+def test_block_dense_long_runs_and_ragged_blocks(dev):
+    """Runs longer than 32 rows are cut into several blocks; blocks of different shapes, rows
+    without edges between them, a non-square adjacency and a non-identity eid."""
+    src, dst = [], []
+    def biclique(rows, cols):
+        for r in rows:
+            for c in cols:
+                src.append(r); dst.append(c)
+    biclique(range(0, 50), range(10, 30))        # 50 rows x 20 ids -> blocks of 32 + 18 rows
+    biclique(range(60, 61), range(0, 32))        # a single row with 32 ids
+    biclique(range(70, 110), range(100, 103))    # 40 rows x 3 ids -> 32 + 8
+    biclique(range(110, 120), range(40, 71))     # 10 rows x 31 ids
+    n_src, n_dst = 120, 130
+    g = graphs.graph_from_coo(torch.tensor(src), torch.tensor(dst), n_src, n_dst, chunk_size=7)
+    gd = g.to(dev)
+    _lib.clear_plan_cache()
+    _lib.tune("dense_min_fill", 1); _lib.tune("dense_detect_min_fill", 1)
+    try:
+        pr, pc = _plans(gd)
+        assert pr.info.n_dense_blocks == 6 and pr.info.max_segment_len == 32
+        assert pc.info.max_segment_len > 32 and pc.info.n_dense_blocks == 0    # columns 10..29 have 50 sources
+        for h, d in ((1, 64), (2, 32), (1, 8)):
+            inp = rand_inputs(g, h, d, seed=3, normal=True)
+            want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+            got = hip_step(gd, *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+            for k in ("s", "a", "o", "dQ", "dK", "dV"):
+                close(got[k], want[k])
+    finally:
+        _lib.tune("dense_min_fill", 40); _lib.tune("dense_detect_min_fill", 10)
+        _lib.clear_plan_cache()
+
+
+def test_block_dense_not_selected_on_irregular_graphs(dev):
+    g = random_graph(300, 300, 3000, seed=1, chunk_size=32).to(dev)
+    _lib.clear_plan_cache()
+    for p in _plans(g):
+        assert p.info.n_dense_blocks == 0 and p.info.dense_fill_pct == 0
