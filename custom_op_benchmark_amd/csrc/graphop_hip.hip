@@ -77,6 +77,8 @@ struct Tuning {
   int dense_blocks;       // use the fp32-MFMA block-dense drivers when the plan found a cover
   int dense_min_fill;     // ... whose 32x32 tiles hold at least this many percent edges
   int dense_detect_min_fill;  // plan creation keeps a block cover only above this fill (percent)
+  int sweep_w;            // > 0: number of column windows (overrides window_kb)
+  int spmm_window_scale;  // window-owner SpMM over identity-eid slots: windows this many times window_kb
   int sweep_mode;         // 0: workgroups own vrows and walk the windows in step (paced sweep);
                           // 1: XCDs own windows, waves pull (window, vrow tile) tasks (window-owner)
   int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
@@ -95,6 +97,8 @@ struct Tuning {
     transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
     sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
     sweep_mode = env_int("GRAPHOP_SWEEP_MODE", 1);
+    sweep_w = env_int("GRAPHOP_SWEEP_W", 0);
+    spmm_window_scale = env_int("GRAPHOP_SPMM_WINDOW_SCALE", 2);
     dense_blocks = env_int("GRAPHOP_DENSE_BLOCKS", 1);
     dense_min_fill = env_int("GRAPHOP_DENSE_MIN_FILL", 40);
     dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
@@ -166,7 +170,7 @@ struct SweepLaunch {
 // Decide whether the window-sweep driver applies and fetch / build its structure.
 // Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
 inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
-                        SweepLaunch* out, int force_windows = 0) {
+                        SweepLaunch* out, int force_windows = 0, bool accumulating = false) {
   const Tuning& t = tuning();
   if (!t.sweep || !plan) return 0;
   const graphop_plan_info_t& pi = plan->info;
@@ -184,7 +188,14 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   auto windows_ok = [&](i64 w) {
     return w >= 2 && w <= t.max_windows && mean_row >= (i64)t.sweep_min_granule * w;
   };
-  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
+  // A window-owner SpMM over identity-eid slots flushes one partial row per (vrow, window): it is
+  // faster with windows of twice the L2 size (half as many flushes, misses served by the Infinity
+  // Cache) and vrows twice as long -- measured on Reddit-shape: 2.25 ms at W=8 vs 2.46 at W=16.
+  const int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
+                      t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
+  i64 W = force_windows ? force_windows
+                        : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024 * coarse));
+  if (!force_windows && t.sweep_w > 0) W = t.sweep_w;   // experiments: window count given directly
   if (!force_windows && !windows_ok(W)) {
     W = table_bytes > (128LL << 20) ? pow2ceil(ceil_div(table_bytes, (i64)t.mall_window_kb * 1024)) : 0;
     if (!windows_ok(W)) return 0;
@@ -203,7 +214,7 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
     i64 target = pi.n_edges / (resident_vrows > 0 ? resident_vrows : 1);
     i64 p2 = 64;
     while (p2 * 2 <= target && p2 < 4096) p2 <<= 1;
-    T = (int)p2;
+    T = (int)(p2 * coarse);
   }
   const Sweep* sw = nullptr;
   const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
@@ -334,7 +345,7 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
                    const void* X, void* out, i64 h, int d4, const graphop_plan* other,
                    i64 n_other_cols, hipStream_t st) {
   SweepLaunch sl;
-  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true);
   if (use != 1) return use;
   bool id = plan->info.eid_identity != 0;
   const float* ww = (const float*)w;
@@ -668,7 +679,7 @@ int graphop_tune(const char* key, int value) {
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
       {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
       {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch},
-      {"sweep_mode", &t.sweep_mode}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
+      {"sweep_mode", &t.sweep_mode}, {"sweep_w", &t.sweep_w}, {"spmm_window_scale", &t.spmm_window_scale}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"transpose_scalars", &t.transpose_scalars}};
   for (auto& e : tab)

@@ -12,7 +12,7 @@ fam = {}
 for name, v in summ.items():
     if not name or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
-    f = re.sub(r"<.*", "", name).replace("_sweep", "")
+    f = re.sub(r"<.*", "", name).replace("_sweep", "").replace("_wown", "")
     e = fam.setdefault(f, {"bytes": 0.0, "n": 0, "variants": {}})
     b = v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024
     e["bytes"] += b; e["n"] += 1

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Re-create the measurements kept under profiles/ (run on the GPU box from the repo root):
+#   bash tools/refresh_profiles.sh <tag>      e.g. r1_final  -> gpurun_out/<tag>_*
+# bench line, rocprofv3 kernel stats of the same command, separate --pmc passes, and the bench
+# lines of the other shapes.  Copy the files you want judged into profiles/.
+set -eo pipefail
+TAG=${1:-r1_final}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+python bench.py --steps 10 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+echo "[refresh] bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o stats -- \
+    python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 \
+    > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err"
+cp "$(find "$OUT/prof_$TAG" -name 'stats_kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+echo "[refresh] kernel stats done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$TAG" -o $c -- \
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pmc_$c.log" 2>&1
+  echo "[refresh] pmc $c done"
+done
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --output-format csv -d "$OUT/pmc_$TAG" -o l2 -- \
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pmc_l2.log" 2>&1
+echo "[refresh] pmc l2 done"
+python tools/pmc_summary.py "$(dirname "$(find "$OUT/pmc_$TAG" -name 'l2_counter_collection.csv' | head -1)")" \
+    FETCH_SIZE WRITE_SIZE l2 > "$OUT/${TAG}_pmc_summary.json"
+python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 > "$OUT/${TAG}_pmc_traffic.json"
+python bench.py --graph harness --d 1024 --heads 1 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_d1024_bench.json" 2>/dev/null
+python bench.py --graph harness --d 64 --heads 8 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_8x64_bench.json" 2>/dev/null
+python bench.py --graph cora --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_cora_bench.json" 2>/dev/null
+echo "[refresh] small shapes done"
+python bench.py --graph products --d 16 --heads 8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d16_bench.json" 2>/dev/null
+python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
+echo "[refresh] all done"
