@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal: build rank 0's shard of a WORLD-way partition and time its "
                          "local compute (collectives replaced by local copies); not a headline number")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture the step once into a HIP graph and time its replays (single GPU; for the "
+                         "launch-bound small shapes -- the headline line is measured with eager API calls)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -203,6 +206,22 @@ def main():
     for _ in range(args.warmup):
         step()
 
+    timed_step = step
+    if args.hip_graph:
+        if runner is not None or world > 1:
+            raise SystemExit("--hip-graph is a single-GPU option")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        Q.grad = K.grad = V.grad = None
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph):
+            functions.attention_step(g, Q, K, V, dO)
+        timed_step = hip_graph.replay
+        timed_step()
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -211,7 +230,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        timed_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -300,6 +319,7 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else "node-range shards x%d, RCCL all-to-all halo" % world)
                                   + (" [EMULATED shard 0 of %d, no collectives]" % args.emulate_world if args.emulate_world > 1 else "")},
         "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3)},
+        "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

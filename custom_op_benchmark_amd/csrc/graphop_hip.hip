@@ -121,6 +121,27 @@ Tuning& tuning_mut() {
 }
 const Tuning& tuning() { return tuning_mut(); }
 
+// Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
+inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  unsigned char* p = (unsigned char*)ptr;
+  const size_t head = (16 - ((uintptr_t)p & 15)) & 15;
+  if (head >= bytes || bytes < 64) {
+    hipLaunchKernelGGL(k_zero1, dim3((unsigned)ceil_div((i64)bytes, 256)), dim3(256), 0, st, p, (i64)bytes);
+    return hipGetLastError();
+  }
+  if (head) hipLaunchKernelGGL(k_zero1, dim3(1), dim3(64), 0, st, p, (i64)head);
+  p += head;
+  const size_t body = bytes - head;
+  const i64 n16 = (i64)(body / 16);
+  const int n_tail = (int)(body % 16);
+  i64 blocks = ceil_div(n16, 256 * 4);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_zero16, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n16, p + n16 * 16, n_tail);
+  return hipGetLastError();
+}
+
 inline size_t esize(int dtype) { return dtype == GRAPHOP_F64 ? 8 : 4; }
 
 inline bool pow2(i64 v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -238,7 +259,7 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
     out->view.K = K;
     out->view.win_bytes = win_cols * row_bytes;
     out->view.table_bytes = table_bytes;
-    if (hipMemsetAsync(out->view.sync, 0, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
+    if (zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
     i64 nb = (i64)t.n_cu * bpc;
     const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
     if (nb > need) nb = need;
@@ -271,7 +292,7 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   const bool paced = t.sweep_drift > 0 && sync_ints <= kSweepSyncInts;
   out->view.sync = paced ? sw->sync : nullptr;
   out->view.drift = paced ? (t.sweep_drift > 3 ? 3 : t.sweep_drift) : 0;   // pacer's LDS ring holds 4 steps
-  if (paced && hipMemsetAsync(sw->sync, 0, sizeof(int) * (size_t)sync_ints, st) != hipSuccess)
+  if (paced && zero_async(sw->sync, sizeof(int) * (size_t)sync_ints, st) != hipSuccess)
     return -GRAPHOP_ERR_HIP;
   out->view.V = sw->V;
   out->view.W = sw->W;
@@ -600,7 +621,7 @@ int softmax_forward_t(const i64* row, const i64* indptr, const i64* eid, const T
                       i64 E, i64 h, T* ws, i64 ws_rows, const graphop_plan* plan, hipStream_t st) {
   const bool owned = plan_matches(plan, row, indptr, eid, C, E) && plan->info.row_owned;
   const bool covered = owned && plan->info.full_coverage && plan->info.eid_identity;
-  if (!covered && E * h > 0) GO_HIP(hipMemsetAsync(y, 0, sizeof(T) * (size_t)(E * h), st));
+  if (!covered && E * h > 0) GO_HIP(zero_async(y, sizeof(T) * (size_t)(E * h), st));
   if (C == 0) return GRAPHOP_OK;
   if (owned) return launch_softmax_seg<T, false>(plan, indptr, eid, x, (const T*)nullptr, y, h, st);
   GO_CHECK_ARG(ws != nullptr && ws_rows > 0,
@@ -611,7 +632,7 @@ int softmax_forward_t(const i64* row, const i64* indptr, const i64* eid, const T
   const unsigned fb = (unsigned)ceil_div(ws_rows * h, 256) > 4096u ? 4096u
                                                                    : (unsigned)ceil_div(ws_rows * h, 256);
   hipLaunchKernelGGL((k_fill<T>), dim3(fb), dim3(256), 0, st, max_val, ws_rows * h, (T)-1e9);
-  GO_HIP(hipMemsetAsync(sum, 0, sizeof(T) * (size_t)(ws_rows * h), st));
+  GO_HIP(zero_async(sum, sizeof(T) * (size_t)(ws_rows * h), st));
   const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
   hipLaunchKernelGGL((k_softmax_max<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr, eid, x,
                      max_val, C, h);
@@ -629,13 +650,13 @@ int softmax_backward_t(const i64* row, const i64* indptr, const i64* eid, const 
                        hipStream_t st) {
   const bool owned = plan_matches(plan, row, indptr, eid, C, E) && plan->info.row_owned;
   const bool covered = owned && plan->info.full_coverage && plan->info.eid_identity;
-  if (!covered && E * h > 0) GO_HIP(hipMemsetAsync(dx, 0, sizeof(T) * (size_t)(E * h), st));
+  if (!covered && E * h > 0) GO_HIP(zero_async(dx, sizeof(T) * (size_t)(E * h), st));
   if (C == 0) return GRAPHOP_OK;
   if (owned) return launch_softmax_seg<T, true>(plan, indptr, eid, y, dy, dx, h, st);
   GO_CHECK_ARG(ws != nullptr && ws_rows > 0,
                "sparse_softmax_backward: the general (plan-less) path needs a workspace of "
                "workspace_rows*h values with workspace_rows > max(row)");
-  GO_HIP(hipMemsetAsync(ws, 0, sizeof(T) * (size_t)(ws_rows * h), st));
+  GO_HIP(zero_async(ws, sizeof(T) * (size_t)(ws_rows * h), st));
   const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
   hipLaunchKernelGGL((k_softmax_bwd_aggre<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr,
                      eid, dy, y, ws, C, h);
@@ -813,7 +834,7 @@ int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* i
                                     n_chunks, n_edges) &&
                        plan->info.full_coverage && plan->info.eid_identity &&
                        plan->info.indptr_monotone;
-  if (!covered) GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
+  if (!covered) GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_edges * h), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, A); GO_PTR(fn, B);
   (void)n_a;
@@ -835,8 +856,8 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   GO_CHECK_ARG(n_col_chunks >= 0 && n_a >= 0 && n_b >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
-  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
-  if (n_b * h * d > 0) { GO_PTR(fn, dB); GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_b * h * d), st)); }
+  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st)); }
+  if (n_b * h * d > 0) { GO_PTR(fn, dB); GO_HIP(zero_async(dB, es * (size_t)(n_b * h * d), st)); }
   if (h * d == 0) return GRAPHOP_OK;
   if (n_row_chunks > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr_r); GO_PTR(fn, eid_r); GO_PTR(fn, indices_r); GO_PTR(fn, B); GO_PTR(fn, dy);
@@ -905,7 +926,7 @@ int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* in
   hipStream_t st = (hipStream_t)stream;
   if (n_y * h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
-  GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_y * h * d), st));
+  GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_y * h * d), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, edata); GO_PTR(fn, x);
   return launch_spmm<false>("spmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
@@ -931,9 +952,9 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
                                       n_row_chunks, n_edges) &&
                          plan_r->info.full_coverage && plan_r->info.eid_identity &&
                          plan_r->info.indptr_monotone;
-    if (!covered) GO_HIP(hipMemsetAsync(dedata, 0, es * (size_t)(n_edges * h), st));
+    if (!covered) GO_HIP(zero_async(dedata, es * (size_t)(n_edges * h), st));
   }
-  if (n_x * h * d > 0) { GO_PTR(fn, dx); GO_HIP(hipMemsetAsync(dx, 0, es * (size_t)(n_x * h * d), st)); }
+  if (n_x * h * d > 0) { GO_PTR(fn, dx); GO_HIP(zero_async(dx, es * (size_t)(n_x * h * d), st)); }
   if (h * d == 0) return GRAPHOP_OK;
   if (n_row_chunks > 0 && n_edges > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, dy); GO_PTR(fn, x);
@@ -966,7 +987,7 @@ int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* 
   const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                                     n_chunks, n_edges) &&
                        plan->info.full_coverage && plan->info.eid_identity && plan->info.indptr_monotone;
-  if (!covered) GO_HIP(hipMemsetAsync(y, 0, esize(dtype) * (size_t)(n_edges * h), st));
+  if (!covered) GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_edges * h), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B);
   if (nme_fast_ok(dtype, h, d, n_edges)) {
@@ -997,10 +1018,10 @@ int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t*
   const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                                     n_chunks, n_edges) &&
                        plan->info.full_coverage && plan->info.eid_identity && plan->info.indptr_monotone;
-  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(hipMemsetAsync(dA, 0, es * (size_t)(n_a * h * d), st)); }
+  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st)); }
   if (n_edges * d > 0) {   // every edge row is written when the chunks cover all slots: skip the E*d zero-fill
     GO_PTR(fn, dB);
-    if (!covered) GO_HIP(hipMemsetAsync(dB, 0, es * (size_t)(n_edges * d), st));
+    if (!covered) GO_HIP(zero_async(dB, es * (size_t)(n_edges * d), st));
   }
   if (n_chunks == 0 || h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B); GO_PTR(fn, dy);

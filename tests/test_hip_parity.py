@@ -514,3 +514,50 @@ def test_block_dense_not_selected_on_irregular_graphs(dev):
     _lib.clear_plan_cache()
     for p in _plans(g):
         assert p.info.n_dense_blocks == 0 and p.info.dense_fill_pct == 0
+
+
+# ---- HIP graph capture ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["irregular", "windowed", "block_dense"])
+def test_step_replays_from_a_captured_hip_graph(dev, shape):
+    """The whole fwd+bwd step (8 library launches + zero fills) captured once into a HIP graph and
+    replayed on new inputs gives what eager execution gives: no op synchronises, allocates outside
+    torch's graph pool or touches host state per call once the plans exist."""
+    forced = shape == "windowed"
+    if forced:
+        _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 4); _lib.tune("vrow_t", 64); _lib.tune("sweep_min_granule", 0)
+    _lib.clear_plan_cache()
+    try:
+        if shape == "block_dense":
+            g = graphs.block_diagonal_graph(6, 30, device=dev)
+        else:
+            g = random_graph(900, 900, 9000, seed=4, chunk_size=32, zero_rows=0.1, hub=400).to(dev)
+        n, d = g.n_src, 64
+        gen = torch.Generator(device=dev).manual_seed(0)
+        Q, K, V = (torch.randn(n, d, device=dev, generator=gen).requires_grad_(True) for _ in range(3))
+        dO = torch.randn(n, d, device=dev, generator=gen)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # warm-up: builds the plans
+            for _ in range(2):
+                functions.attention_step(g, Q, K, V, dO)
+        torch.cuda.current_stream().wait_stream(side)
+        for t_ in (Q, K, V):
+            t_.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            s, a, o = functions.attention_step(g, Q, K, V, dO)
+        outs = (s, a, o, Q.grad, K.grad, V.grad)
+        for trial in range(2):
+            with torch.no_grad():
+                for t_ in (Q, K, V, dO):
+                    t_.copy_(torch.randn(n, d, device=dev, generator=gen))
+            graph.replay()
+            torch.cuda.synchronize()
+            got = [x.clone() for x in outs]
+            ref = hip_step(g, Q.detach(), K.detach(), V.detach(), dO)
+            for x, k in zip(got, ("s", "a", "o", "dQ", "dK", "dV")):
+                torch.testing.assert_close(x, ref[k], rtol=1e-4, atol=1e-5)
+    finally:
+        if forced:
+            _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0); _lib.tune("sweep_min_granule", 4)
+        _lib.clear_plan_cache()
