@@ -212,14 +212,17 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   // A window-owner SpMM over identity-eid slots flushes one partial row per (vrow, window): it is
   // faster with windows of twice the L2 size (half as many flushes, misses served by the Infinity
   // Cache) and vrows twice as long -- measured on Reddit-shape: 2.25 ms at W=8 vs 2.46 at W=16.
-  const int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
-                      t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
-  i64 W = force_windows ? force_windows
-                        : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024 * coarse));
+  int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
+                t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
+  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
   if (!force_windows && t.sweep_w > 0) W = t.sweep_w;   // experiments: window count given directly
   if (!force_windows && !windows_ok(W)) {
+    coarse = 1;   // Infinity-Cache tier: windows are sized for that cache, not for the flush count
     W = table_bytes > (128LL << 20) ? pow2ceil(ceil_div(table_bytes, (i64)t.mall_window_kb * 1024)) : 0;
     if (!windows_ok(W)) return 0;
+  } else if (!force_windows && t.sweep_w <= 0 && coarse > 1) {
+    const i64 Wc = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024 * coarse));
+    if (Wc >= 2) W = Wc; else coarse = 1;
   }
   if (W < 2 || W > t.max_windows) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);

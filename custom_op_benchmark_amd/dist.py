@@ -12,6 +12,9 @@ asks for it.  Design:
   n_own x (n_own + n_halo) chunked CSR and runs through the unchanged single-GPU operators.
 * Forward exchange: a variable-size all_to_all delivers the halo rows of K (and one more those of
   V) straight into the tail of preallocated extended tensors -- no packing, no concatenation.
+  Both are started together (async); the V rows are awaited only in front of the SpMM, and the
+  returning dV rows travel under the softmax / SDDMM backward: two of the four exchanges overlap
+  with compute.
   Backward exchange: the partial dK / dV rows computed for halo columns (a contiguous slice of the
   operators' outputs) travel back with the transposed split sizes and are added into the owners' rows.
   xGMI is point-to-point: all_to_all drives all 7 links of a GPU at once; no ring collective.
@@ -40,6 +43,14 @@ def balanced_ranges(out_degree, world):
         bounds.append(min(max(b, bounds[-1]), n))
     bounds.append(n)
     return bounds
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+_DONE = _Done()
 
 
 class ShardedAttention:
@@ -97,37 +108,48 @@ class ShardedAttention:
         dist.all_to_all_single(t_out, t_in, group=self.group)
         return t_out.tolist()
 
-    def _all_to_all(self, out, inp, out_splits, in_splits):
+    def _all_to_all(self, out, inp, out_splits, in_splits, async_op=False):
+        """Variable-size all-to-all (splits count rows).  Returns a handle whose wait() orders the
+        current stream (RCCL) / the caller (gloo) after the exchange; already complete unless
+        async_op was requested on a real process group."""
         if self.world == 1:
             out.copy_(inp)
-            return
+            return _DONE
         if self.emulate:
             n = min(out.shape[0], inp.shape[0])
             out[:n].copy_(inp[:n])
             if out.shape[0] > n:
                 out[n:].zero_()
-            return
+            return _DONE
         if out.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
             o, i = out.cpu(), inp.cpu()
             dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
             out.copy_(o)
-            return
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)   # splits count rows
+            return _DONE
+        work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+        return work if async_op else _DONE
 
-    def gather_halo_into(self, X_own, X_ext):
+    def gather_halo_into(self, X_own, X_ext, async_op=False):
         """X_ext[:n_own] = X_own; X_ext[n_own:] = rows of X for the halo nodes, fetched from their
-        owners straight into the tail of the (preallocated) extended tensor -- no concatenation."""
+        owners straight into the tail of the (preallocated) extended tensor -- no concatenation.
+        With async_op the exchange is only started: call wait() on the returned handle before the
+        halo rows are read."""
         n_own = self.n_own
         X_ext[:n_own].copy_(X_own)
         send = X_own[self.serve_rows].contiguous()
-        self._all_to_all(X_ext[n_own:], send, self.recv_counts, self.send_counts)
-        return X_ext
+        return self._all_to_all(X_ext[n_own:], send, self.recv_counts, self.send_counts, async_op)
+
+    def scatter_halo_grad_start(self, dX_own, dX_halo, async_op=False):
+        """Start sending the partial gradient rows of halo nodes back to their owners."""
+        recv = dX_own.new_empty((int(self.serve_rows.numel()),) + tuple(dX_own.shape[1:]))
+        handle = self._all_to_all(recv, dX_halo.contiguous(), self.send_counts, self.recv_counts, async_op)
+        return handle, recv
 
     def scatter_halo_grad(self, dX_own, dX_halo):
         """Send partial gradient rows of halo nodes back to their owners and add them there."""
-        recv = dX_own.new_empty((int(self.serve_rows.numel()),) + tuple(dX_own.shape[1:]))
-        self._all_to_all(recv, dX_halo.contiguous(), self.send_counts, self.recv_counts)
+        handle, recv = self.scatter_halo_grad_start(dX_own, dX_halo)
+        handle.wait()
         dX_own.index_add_(0, self.serve_rows, recv)
         return dX_own
 
@@ -154,24 +176,35 @@ class ShardedAttention:
         ops, g = self._ops(), self.graph
         Qd, Kd, Vd = Q.detach().contiguous(), K.detach(), V.detach()
         n_own = self.n_own
-        # forward exchange: halo rows of K and of V land directly behind the own rows
-        K_ext = self.gather_halo_into(Kd, self._ext_buffer("K", Kd))
-        V_ext = self.gather_halo_into(Vd, self._ext_buffer("V", Vd))
+        # forward exchange: halo rows of K and of V land directly behind the own rows.  Both are
+        # started at once; the V rows are only awaited in front of the SpMM, so that exchange
+        # runs under the SDDMM and the softmax.
+        K_ext, V_ext = self._ext_buffer("K", Kd), self._ext_buffer("V", Vd)
+        wait_k = self.gather_halo_into(Kd, K_ext, async_op=True)
+        wait_v = self.gather_halo_into(Vd, V_ext, async_op=True)
         a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
         a8 = g.csr_args()
+        wait_k.wait()
         s = ops.maskedmm_csr_forward(*a4, Qd, K_ext)
         a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+        wait_v.wait()
         o_ext = ops.vector_spmm_forward(*a4, a, V_ext)          # (n_ext, ...) ; rows >= n_own are 0
         o = o_ext[:n_own]
         # dy is only indexed by row ids (< n_own): no need to pad it to the extended row count
         da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
+        # backward exchange: partial rows computed for halo columns go home and are added there;
+        # the dV rows travel while the softmax and SDDMM backward run
+        exchange = self.n_halo or self.world > 1
+        dV = dV_ext[:n_own]                                     # views: updated in place
+        if exchange:
+            wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True)
         ds = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
         dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd, K_ext, ds)
-        # backward exchange: partial rows computed for halo columns go home and are added there
-        dK, dV = dK_ext[:n_own], dV_ext[:n_own]                  # views: updated in place
-        if self.n_halo or self.world > 1:
+        dK = dK_ext[:n_own]
+        if exchange:
             self.scatter_halo_grad(dK, dK_ext[n_own:])
-            self.scatter_halo_grad(dV, dV_ext[n_own:])
+            wait_dv.wait()
+            dV.index_add_(0, self.serve_rows, recv_dv)
         for t, gr in ((Q, dQ), (K, dK), (V, dV)):
             if t.requires_grad:
                 t.grad = gr
