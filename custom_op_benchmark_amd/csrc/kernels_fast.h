@@ -347,12 +347,15 @@ struct StripMap {   // flat slot j of the strip -> (granule k, slot e); all grou
 };
 
 // SDDMM strip: y[eid[e]*h + head] = <A_k, B[idx[e]]> ; A rows of the group's K vrows are in LDS.
-template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
+// `stage_rows()` is called once the ids of the first batch have been requested: the caller puts
+// the A rows into LDS there, so their fetch overlaps the id fetch instead of preceding it.
+struct NoStage { __device__ __forceinline__ void operator()() const {} };
+template <int L, int NV, bool H1, bool EID_ID, bool OFF32, typename Stage = NoStage>
 __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, int lo_l, int n_l,
                                             const int* __restrict__ eid32,
                                             const int* __restrict__ idx32,
                                             const float* __restrict__ B, float* __restrict__ y,
-                                            int h, int d4, int l) {
+                                            int h, int d4, int l, Stage&& stage_rows = Stage()) {
   constexpr int SB = StripCfg<L, NV>::SB;
   constexpr i64 F4 = (i64)L * NV;
   StripMap m;
@@ -370,6 +373,7 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       nsrc = __builtin_nontemporal_load(idx32 + e);
     }
   }
+  stage_rows();
   // h == 1: the batch's 16 results are stored AFTER the next batch's rows have been requested.
   // vmcnt retires in issue order, so a store issued ahead of those loads would have to be
   // acknowledged (a write to HBM) before their data could be used.
@@ -811,6 +815,29 @@ struct WownQueue {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     x = (int)(xcc & (kSyncXcds - 1));
   }
+  // Split form of pull(): issue() starts the dequeue on the current queue (the returned word is
+  // not waited for), resolve() -- a whole task later -- decodes it, falling back to the blocking
+  // pull() when that queue turned out to be drained.
+  __device__ __forceinline__ int issue() {
+    int raw = -1;
+    if (s < kSyncXcds && (threadIdx.x & (kWave - 1)) == 0)
+      raw = __hip_atomic_fetch_add(q + (i64)((x + s) & (kSyncXcds - 1)) * kSyncStride, 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    return raw;
+  }
+  __device__ __forceinline__ bool resolve(int raw, int& w, int& t) {
+    if (s >= kSyncXcds) return false;
+    const int y = (x + s) & (kSyncXcds - 1);
+    const int nwin = (W - y + kSyncXcds - 1) / kSyncXcds;
+    const int idx = __shfl(raw, 0);
+    if (idx >= 0 && idx < nwin * ntasks) {
+      w = y + kSyncXcds * (idx / ntasks);
+      t = idx % ntasks;
+      return true;
+    }
+    ++s;
+    return pull(w, t);
+  }
   // wave-uniform; every lane calls.  Returns false when all eight queues are drained.
   __device__ __forceinline__ bool pull(int& w, int& t) {
     while (s < kSyncXcds) {
@@ -833,6 +860,24 @@ struct WownQueue {
   }
 };
 
+// Bounds of one (window, vrow tile) task for this lane group: lane k < nv holds vrow k's slot range
+// inside the window and its row id.
+struct WownTask {
+  int lo, hi, row, nv;
+  __device__ __forceinline__ void load(const SweepView& s, int w, int t, int tile, int g_in_wave, int l) {
+    const i64 v0 = (i64)t * tile + (i64)g_in_wave * s.K;
+    nv = v0 >= s.V ? 0 : ((s.V - v0) < s.K ? (int)(s.V - v0) : s.K);
+    lo = hi = row = 0;
+    if (l < nv) {
+      lo = s.wp_lo[(i64)w * s.V + v0 + l];
+      hi = s.wp_hi[(i64)w * s.V + v0 + l];
+      row = s.vr_row[v0 + l];
+    }
+  }
+};
+
+// Task pipeline of both kernels: the id of task i+2 is being dequeued and the bounds of task i+1
+// are being fetched while task i runs, so a task starts with its bounds in registers.
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
 __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
@@ -848,26 +893,27 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f3
   WownQueue queue(s, (s.V + tile - 1) / tile);
   int w, t;
   bool more = queue.pull(w, t);
+  int raw = more ? queue.issue() : -1;
+  WownTask cur, nxt;
+  if (more) cur.load(s, w, t, tile, g_in_wave, l);
   while (more) {
-    const i64 v0 = (i64)t * tile + (i64)g_in_wave * s.K;
-    const int nv = v0 >= s.V ? 0 : ((s.V - v0) < s.K ? (int)(s.V - v0) : s.K);
-    int lo_l = 0, hi_l = 0, row_l = 0;
-    if (l < nv) {
-      lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
-      hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
-      row_l = s.vr_row[v0 + l];
-    }
-    int wn, tn;
-    more = queue.pull(wn, tn);    // next task id: its latency hides behind this task's strip
-    for (int k = 0; k < nv; ++k) {
-      const i64 row = __shfl(row_l, k, L);
-      if (__shfl(hi_l - lo_l, k, L) == 0) continue;   // group-uniform
+    int wn = 0, tn = 0;
+    const bool more_n = queue.resolve(raw, wn, tn);
+    raw = more_n ? queue.issue() : -1;
+    nxt.nv = 0; nxt.lo = nxt.hi = nxt.row = 0;
+    if (more_n) nxt.load(s, wn, tn, tile, g_in_wave, l);
+    auto stage_rows = [&]() {   // A rows of this task's non-empty granules -> LDS
+      for (int k = 0; k < cur.nv; ++k) {
+        const i64 row = __shfl(cur.row, k, L);
+        if (__shfl(cur.hi - cur.lo, k, L) == 0) continue;   // group-uniform
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
-        mine[(k * NV + v) * L + l] = ld4_nt(A, row * F4 + v * L + l);
-    }
-    sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, lo_l, hi_l - lo_l, s.eid32, s.idx32, B, y, h, d4, l);
-    w = wn; t = tn;
+        for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4_nt(A, row * F4 + v * L + l);
+      }
+    };
+    sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, cur.lo, cur.hi - cur.lo, s.eid32, s.idx32, B, y, h, d4, l,
+                                          stage_rows);
+    cur = nxt;
+    more = more_n;
   }
 }
 
@@ -885,23 +931,23 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_wown_f32
   WownQueue queue(s, (s.V + tile - 1) / tile);
   int w, t;
   bool more = queue.pull(w, t);
+  int raw = more ? queue.issue() : -1;
+  WownTask cur, nxt;
+  if (more) cur.load(s, w, t, tile, g_in_wave, l);
   while (more) {
-    const i64 v0 = (i64)t * tile + (i64)g_in_wave * s.K;
-    const int nv = v0 >= s.V ? 0 : ((s.V - v0) < s.K ? (int)(s.V - v0) : s.K);
-    int lo_l = 0, hi_l = 0, row_l = 0;
-    if (l < nv) {
-      lo_l = s.wp_lo[(i64)w * s.V + v0 + l];
-      hi_l = s.wp_hi[(i64)w * s.V + v0 + l];
-      row_l = s.vr_row[v0 + l];
-    }
-    int wn, tn;
-    more = queue.pull(wn, tn);
+    int wn = 0, tn = 0;
+    const bool more_n = queue.resolve(raw, wn, tn);
+    raw = more_n ? queue.issue() : -1;
+    nxt.nv = 0; nxt.lo = nxt.hi = nxt.row = 0;
+    if (more_n) nxt.load(s, wn, tn, tile, g_in_wave, l);
     // a granule's sum goes straight to the output row: one dense atomic flush per (vrow, window)
+    const int row_l = cur.row;
     auto to_out = [&](int k, const float4 (&acc)[NV]) {
       atomic_flush_dense<L, NV>(out, __shfl(row_l, k, L), acc, l);
     };
-    spmm_strip<L, NV, H1, EID_ID, OFF32>(to_out, lo_l, hi_l - lo_l, s.eid32, s.idx32, wgt, X, h, hv, l);
-    w = wn; t = tn;
+    spmm_strip<L, NV, H1, EID_ID, OFF32>(to_out, cur.lo, cur.hi - cur.lo, s.eid32, s.idx32, wgt, X, h, hv, l);
+    cur = nxt;
+    more = more_n;
   }
 }
 
