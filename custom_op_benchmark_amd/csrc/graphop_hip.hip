@@ -436,9 +436,24 @@ inline int try_sddmm_block(const char* tag, int dtype, const graphop_plan* plan,
   return 1;
 }
 
+inline bool spmm_block_applies(int dtype, const graphop_plan* plan, i64 n_table_rows, const void* X,
+                               const void* out, i64 h, i64 d) {
+  return block_ok(plan, dtype, h, d, n_table_rows) && d % 32 == 0 && aligned16(X) && aligned16(out);
+}
+// The block-dense SpMM writes every feature of every row that has a segment, with plain stores:
+// when the plan's segments are exactly the rows [0, n_out_rows) the output needs no zero fill.
+inline bool spmm_block_writes_all(int dtype, const i64* row, const i64* indptr, const i64* eid,
+                                  const i64* indices, i64 C, i64 E, const graphop_plan* plan,
+                                  i64 n_table_rows, const void* X, const void* out, i64 h, i64 d,
+                                  i64 n_out_rows) {
+  return plan_matches_full(plan, row, indptr, eid, indices, C, E) &&
+         spmm_block_applies(dtype, plan, n_table_rows, X, out, h, d) && plan->info.rows_sorted &&
+         plan->info.n_segments == n_out_rows && plan->info.max_row == n_out_rows - 1;
+}
+
 inline int try_spmm_block(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows,
                           const void* w, const void* X, void* out, i64 h, i64 d, hipStream_t st) {
-  if (!block_ok(plan, dtype, h, d, n_table_rows) || d % 32 != 0 || !aligned16(X) || !aligned16(out)) return 0;
+  if (!spmm_block_applies(dtype, plan, n_table_rows, X, out, h, d)) return 0;
   const int vw = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);
   const i64 groups = d / (32 * vw);
   const int nw = (int)(groups < 4 ? groups : 4);
@@ -859,8 +874,18 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   GO_CHECK_ARG(n_col_chunks >= 0 && n_a >= 0 && n_b >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
-  if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st)); }
-  if (n_b * h * d > 0) { GO_PTR(fn, dB); GO_HIP(zero_async(dB, es * (size_t)(n_b * h * d), st)); }
+  if (n_a * h * d > 0) {
+    GO_PTR(fn, dA);
+    if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r,
+                               n_row_chunks, n_edges, plan_r, n_b, B, dA, h, d, n_a))
+      GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st));
+  }
+  if (n_b * h * d > 0) {
+    GO_PTR(fn, dB);
+    if (!spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c,
+                               n_col_chunks, n_edges, plan_c, n_a, A, dB, h, d, n_b))
+      GO_HIP(zero_async(dB, es * (size_t)(n_b * h * d), st));
+  }
   if (h * d == 0) return GRAPHOP_OK;
   if (n_row_chunks > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr_r); GO_PTR(fn, eid_r); GO_PTR(fn, indices_r); GO_PTR(fn, B); GO_PTR(fn, dy);
@@ -929,7 +954,9 @@ int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* in
   hipStream_t st = (hipStream_t)stream;
   if (n_y * h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
-  GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_y * h * d), st));
+  if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices,
+                             n_chunks, n_edges, plan, n_x, x, y, h, d, n_y))
+    GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_y * h * d), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, edata); GO_PTR(fn, x);
   return launch_spmm<false>("spmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
@@ -957,7 +984,12 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
                          plan_r->info.indptr_monotone;
     if (!covered) GO_HIP(zero_async(dedata, es * (size_t)(n_edges * h), st));
   }
-  if (n_x * h * d > 0) { GO_PTR(fn, dx); GO_HIP(zero_async(dx, es * (size_t)(n_x * h * d), st)); }
+  if (n_x * h * d > 0) {
+    GO_PTR(fn, dx);
+    if (!spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t,
+                               n_col_chunks, n_edges, plan_c, n_dy, dy, dx, h, d, n_x))
+      GO_HIP(zero_async(dx, es * (size_t)(n_x * h * d), st));
+  }
   if (h * d == 0) return GRAPHOP_OK;
   if (n_row_chunks > 0 && n_edges > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, dy); GO_PTR(fn, x);
