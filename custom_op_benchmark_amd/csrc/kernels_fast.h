@@ -369,8 +369,8 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
     int e;
     m.locate<L>(j < m.total ? j : m.total - 1, nk, e);   // every lane takes part in the shuffles
     if (l < SB && j < m.total) {
-      ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
-      nsrc = __builtin_nontemporal_load(idx32 + e);
+      ne = EID_ID ? e : (*(eid32 + e));
+      nsrc = (*(idx32 + e));
     }
   }
   stage_rows();
@@ -401,7 +401,7 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       }
     }
     if constexpr (H1) {
-      if (prev_e >= 0) __builtin_nontemporal_store(prev_res, y + prev_e);
+      if (prev_e >= 0) y[prev_e] = prev_res;
     }
     // ids of the next batch (issued after the row requests so they stay in flight behind them)
     ne = -1;
@@ -410,8 +410,8 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       int e;
       m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
       if (l < SB && j < m.total) {
-        ne = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
-        nsrc = __builtin_nontemporal_load(idx32 + e);
+        ne = EID_ID ? e : (*(eid32 + e));
+        nsrc = (*(idx32 + e));
       }
     }
     float res = 0.f;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
     }
   }
   if constexpr (H1) {
-    if (prev_e >= 0) __builtin_nontemporal_store(prev_res, y + prev_e);
+    if (prev_e >= 0) y[prev_e] = prev_res;
   }
 }
 
@@ -499,10 +499,10 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
     if (l < SB) {
       // slots past the end re-read the strip's last neighbour id with weight 0 (a row that is in
       // the sum anyway), so the batch loop needs no per-slot clamping
-      p.src = __builtin_nontemporal_load(idx32 + e);
+      p.src = (*(idx32 + e));
       if (j < m.total) {
-        p.e = EID_ID ? e : __builtin_nontemporal_load(eid32 + e);
-        if constexpr (H1 && EID_ID) p.w = __builtin_nontemporal_load(w + p.e);
+        p.e = EID_ID ? e : (*(eid32 + e));
+        if constexpr (H1 && EID_ID) p.w = (*(w + p.e));
       }
     }
   };
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f3
         const i64 row = __shfl(cur.row, k, L);
         if (__shfl(cur.hi - cur.lo, k, L) == 0) continue;   // group-uniform
 #pragma unroll
-        for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4_nt(A, row * F4 + v * L + l);
+        for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
       }
     };
     sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, cur.lo, cur.hi - cur.lo, s.eid32, s.idx32, B, y, h, d4, l,
