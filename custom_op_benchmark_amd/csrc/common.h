@@ -74,7 +74,8 @@ struct Sweep {
   int* queues = nullptr;  // [kQueueRing][8 * 64] task-queue heads of the window-owner drivers
   unsigned queue_next = 0;  // next ring slot (taken under the plan's sweep mutex)
 };
-constexpr long long kLongSegment = 512;    // rows above this many slots get a whole workgroup in softmax
+constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
+constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)
 constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
 // Every window-owner launch takes the next of kQueueRing sets of queue heads, so launches that
 // overlap on different streams never share one (a set is reused 64 launches later).

@@ -610,7 +610,7 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
     const int G = seg_group_width(p->info.n_edges * h / S, h);
     const int n_long = (int)p->n_long;
     const unsigned nb = blocks_for(S, kFastBlock / G) + (unsigned)n_long;
-    const i64 long_len = n_long > 0 ? kLongSegment : (i64)1 << 62;
+    const i64 long_len = n_long > 0 ? (BWD ? kLongSegmentBwd : kLongSegment) : (i64)1 << 62;
 #define GO_SEG(GW, ID)                                                                           \
   if constexpr (!BWD)                                                                            \
     hipLaunchKernelGGL((k_softmax_fwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \

@@ -23,7 +23,8 @@
 //    loop; a per-XCD soft barrier (SweepPacer) keeps all resident waves within `drift` windows.
 //    The gather then runs at L2 rate instead of Infinity-Cache rate.
 //  * k_softmax_*_seg   per-row softmax / its backward over row segments from the plan: rows up
-//    to G*8 items in registers, rows above 512 slots one workgroup each (same launch), shuffle /
+//    to G*16 (forward) / G*32 (backward) items in registers, rows above 1024 / 2048 slots one
+//    workgroup each (same launch), shuffle /
 //    LDS reductions, no atomics, no scratch.
 #pragma once
 #include "common.h"
@@ -1140,7 +1141,10 @@ __global__ __launch_bounds__(kFastBlock) void k_scatter_scalars_sweep(
 // the flattened (slot, head) pairs so that for eid == identity the reads are fully coalesced.
 // Requires G % h == 0 (then a lane always sees the same head t = lane % h).
 // Semantics: graphop_kernel.cu:170-202 (m starts at -1e9, :428).
-constexpr int kSoftmaxCache = 8;   // items per lane kept in registers (rows up to G*8 items: one read)
+// items per lane kept in registers (rows up to G*R items are read once).  Measured on Reddit-shape
+// (mean row 492, 23 % of the rows above 512): forward best at 16, backward at 32.
+constexpr int kSoftmaxCacheFwd = 16;
+constexpr int kSoftmaxCacheBwd = 32;
 
 template <typename T>
 __device__ __forceinline__ T neg_inf();
@@ -1153,7 +1157,7 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
     i64 long_len, i64 block) {
-  constexpr int R = kSoftmaxCache;
+  constexpr int R = kSoftmaxCacheFwd;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
@@ -1234,7 +1238,7 @@ __device__ __forceinline__ void softmax_bwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
     T* __restrict__ dx, i64 n_seg, int h, i64 long_len, i64 block) {
-  constexpr int R = kSoftmaxCache;
+  constexpr int R = kSoftmaxCacheBwd;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
@@ -1342,10 +1346,11 @@ template <typename T, bool BWD, bool EID_ID>
 __device__ __forceinline__ void softmax_long_body(
     const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk,
     const i64* __restrict__ indptr, const i64* __restrict__ eid, const T* __restrict__ in0,
-    const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s) {
+    const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s, i64 long_len) {
   constexpr int RB = kBlockCache;
   const i64 s = long_segs[blockIdx.x];
   const i64 e0 = indptr[seg_chunk[s]];
+  if (indptr[seg_chunk[s + 1]] - e0 <= long_len) return;   // block-uniform: the per-row groups take it
   const i64 items = (indptr[seg_chunk[s + 1]] - e0) * h;
   const int tid = threadIdx.x, t = tid % h;
   auto offs = [&](i64 q) -> i64 {   // 256 % h == 0, so q % h == t for every q of this thread
@@ -1448,7 +1453,7 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
   __shared__ T sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
     softmax_long_body<T, false, EID_ID>(long_segs, seg_chunk, indptr, eid, x, (const T*)nullptr, y, h,
-                                        sh_m, sh_s);
+                                        sh_m, sh_s, long_len);
   else
     softmax_fwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, x, y, n_seg, h, long_len,
                                        (i64)blockIdx.x - n_long);
@@ -1463,7 +1468,7 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
   __shared__ T sh_m[kFastBlock];
   __shared__ T sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_long_body<T, true, EID_ID>(long_segs, seg_chunk, indptr, eid, y, dy, dx, h, sh_m, sh_s);
+    softmax_long_body<T, true, EID_ID>(long_segs, seg_chunk, indptr, eid, y, dy, dx, h, sh_m, sh_s, long_len);
   else
     softmax_bwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, y, dy, dx, n_seg, h, long_len,
                                        (i64)blockIdx.x - n_long);
