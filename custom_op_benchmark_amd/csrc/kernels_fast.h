@@ -7,7 +7,7 @@
 //  * sddmm_range / spmm_range   (chunk drivers) per-edge dots / weighted accumulation over a slot
 //    range [lo, hi) of one row: ids of up to 16 slots are loaded coalesced by the group and
 //    broadcast with ds_bpermute; U neighbour rows (16 B/lane each) are in flight per group.
-//  * sddmm_strip / spmm_strip   (sweep drivers) the K granules a group owns inside one window,
+//  * sddmm_strip / spmm_strip   (window drivers) the K granules a group owns inside one window,
 //    walked as ONE flat slot list in full 16-slot batches with the ids of the next batch(es) in
 //    flight behind the current batch's row requests; rows come in through scalar-base +
 //    32-bit-offset loads; the SDDMM batch is a single basic block.
@@ -16,16 +16,18 @@
 //  * k_sddmm_f32 / k_spmm_f32   CHUNK drivers: work unit = the caller's chunk list; correct for
 //    any chunk layout (SpMM keeps the running row sum in registers while the row id does not
 //    change and merges with native global_atomic_add_f32, 256 contiguous bytes per group).
-//  * k_sddmm_sweep_f32 / k_spmm_sweep_f32   WINDOW-SWEEP drivers (need a plan): the gathered
-//    table is cut into W column windows (<= 4 MB, so the window being gathered from stays in every
-//    XCD's 4 MiB L2; 32 MB Infinity-Cache windows for tables beyond 128 MB); every lane group owns
-//    K (pieces of) rows, keeps their A rows / partial sums in LDS and walks windows in the OUTER
-//    loop; a per-XCD soft barrier (SweepPacer) keeps all resident waves within `drift` windows.
-//    The gather then runs at L2 rate instead of Infinity-Cache rate.
+//  * COLUMN-WINDOW drivers (need a plan): the gathered table is cut into W column windows (<= 4 MB,
+//    the size of an XCD's L2; 32 MB Infinity-Cache windows for tables beyond 128 MB), a row's slots
+//    inside a window are one contiguous range.  Two loop orders over (window, vrow):
+//      k_sddmm_wown_f32 / k_spmm_wown_f32    (default) every XCD owns the windows x, x+8, ... and
+//        its waves pull (window, tile of vrows) tasks from a per-XCD queue; a window lives in one
+//        L2 only; SpMM hands each granule sum to the output with a dense atomic flush;
+//      k_sddmm_sweep_f32 / k_spmm_sweep_f32  every lane group owns K vrows (A rows / partial sums
+//        in LDS) and all walk the windows together, kept within `drift` windows by a per-XCD
+//        soft barrier (SweepPacer).
 //  * k_softmax_*_seg   per-row softmax / its backward over row segments from the plan: rows up
 //    to G*16 (forward) / G*32 (backward) items in registers, rows above 1024 / 2048 slots one
-//    workgroup each (same launch), shuffle /
-//    LDS reductions, no atomics, no scratch.
+//    workgroup each (same launch), shuffle / LDS reductions, no atomics, no scratch.
 #pragma once
 #include "common.h"
 
