@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the step once into a HIP graph and time its replays (single GPU; for the "
                          "launch-bound small shapes -- the headline line is measured with eager API calls)")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary measurement of the fused op")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -246,6 +247,30 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_edges * args.steps / elapsed
 
+    # ---- the same step through the fused op (extra op: one autograd node, no E-sized intermediates) ----
+    fused = None
+    if runner is None and world == 1 and not args.no_fused and not args.hip_graph:
+        def fstep():
+            Q.grad = K.grad = V.grad = None
+            functions.fused_attention_step(g, Q, K, V, dO)
+        for _ in range(max(2, args.warmup)):
+            fstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        torch.cuda.synchronize()
+        f_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        _lib.profile_enable(True)
+        for _ in range(max(1, args.profile_steps)):
+            fstep()
+        torch.cuda.synchronize()
+        fprof = _lib.profile_read()
+        _lib.profile_enable(False)
+        fused = {"ms_per_step": round(f_ms, 4), "value": g.n_edges / (f_ms * 1e-3), "unit": "edges/s",
+                 "op": "FusedAttention (attention_forward / attention_backward)",
+                 "passes_ms": {k: round(v["mean_ms"], 4) for k, v in fprof.items()}}
+
     # ---- per-kernel durations, live, hipEvents on the launch stream --------------------------------
     _lib.profile_enable(True)
     for _ in range(max(1, args.profile_steps)):
@@ -322,6 +347,8 @@ def main():
         "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }
+    if fused is not None:
+        out["fused"] = fused
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, Q.detach(), K.detach(), V.detach(), dO, args.cpu_sample_edges, log)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

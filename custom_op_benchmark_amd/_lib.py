@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -53,6 +53,10 @@ _SIGNATURES = {
     "graphop_vector_spmm_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_node_mul_edge_forward": [ctypes.c_int] + [_P] * 6 + [_c64] * 5 + [_P, _P],
     "graphop_node_mul_edge_backward": [ctypes.c_int] + [_P] * 8 + [_c64] * 5 + [_P, _P],
+    "graphop_attention_workspace_bytes": [ctypes.c_int, ctypes.c_int] + [_c64] * 5 + [_P, _P, _P,
+                                                                                       ctypes.POINTER(_c64)],
+    "graphop_attention_forward": [ctypes.c_int] + [_P] * 9 + [_c64] * 6 + [_P, _c64, _P, _P],
+    "graphop_attention_backward": [ctypes.c_int] + [_P] * 17 + [_c64] * 7 + [_P, _c64, _P, _P, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["graphop_abi_version", "graphop_last_error",
                                                "graphop_plan_destroy"])

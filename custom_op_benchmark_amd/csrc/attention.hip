@@ -1,0 +1,243 @@
+// Fused attention step (extra op next to the reference's eight):
+//   forward : o = vector_spmm(sparse_softmax(maskedmm_csr(Q, K)), V), leaving only o and the row
+//             statistics (max, 1 / sum) behind -- s and a live in the caller's workspace;
+//   backward: dQ, dK, dV from (Q, K, V, o, stats, dO) by two fused window-owner passes
+//             (kernels_attn.h) that recompute a and ds per slot; when those do not apply (no plan,
+//             unsorted rows, fp64, several heads, tiny tables) the same result comes from the
+//             composition of the unfused entry points, with the intermediates in the workspace.
+// Reference composition: wrapper.py:20-30 (MaskedMMCSR), :8-18 (SparseSoftmax), :44-55 (VectorSPMM).
+#include "common.h"
+#include "host.h"
+#include "kernels_attn.h"
+
+namespace graphop {
+namespace {
+
+// resident workgroups per CU the fused kernels are compiled for: the column-major pass carries two
+// accumulators and the statistics pipeline and needs more than 128 VGPRs
+constexpr int kAttnBpcRow = 4;
+constexpr int kAttnBpcCol = 3;
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct AttnFast {
+  SweepLaunch r, c;   // row-major pass (gathers K|V), column-major pass (gathers Q|dO)
+};
+
+// Do the fused window-owner passes apply?  1 = yes (launch geometry in *out), 0 = no, < 0 = error.
+// dry_run: only decide (and build the cached window structures), take no task queue.
+int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const graphop_plan* plan_r,
+                   const graphop_plan* plan_c, hipStream_t st, bool dry_run, AttnFast* out) {
+  const Tuning& t = tuning();
+  if (!t.attn_fused || t.force_generic || dtype != GRAPHOP_F32 || h != 1) return 0;
+  if (!plan_r || !plan_c || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024) return 0;
+  if (n_edges >= 0x7fffffffLL || n_q >= 0x7fffffffLL || n_k >= 0x7fffffffLL || n_edges == 0) return 0;
+  if (plan_r->info.max_row >= n_q || plan_r->info.max_index >= n_k || plan_c->info.max_row >= n_k ||
+      plan_c->info.max_index >= n_q)
+    return 0;
+  int use_r = 0, use_c = 0;
+  GO_DISPATCH_LNV((int)d, {
+    SweepOpts o;
+    o.row_bytes = 2 * 16LL * L * NV;
+    o.K = t.attn_k > 0 ? t.attn_k : (4 / NV > 0 ? 4 / NV : 1);
+    o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
+    o.require_owner = 1;
+    o.dry_run = dry_run ? 1 : 0;
+    o.bpc = (t.attn_bpc > 0 && t.attn_bpc < kAttnBpcRow) ? t.attn_bpc : kAttnBpcRow;
+    use_r = choose_sweep(plan_r, n_k, L, NV, st, &out->r, 0, true, &o);
+    o.bpc = (t.attn_bpc > 0 && t.attn_bpc < kAttnBpcCol) ? t.attn_bpc : kAttnBpcCol;
+    if (use_r == 1) use_c = choose_sweep(plan_c, n_q, L, NV, st, &out->c, 0, true, &o);
+  });
+  if (use_r < 0) return use_r;
+  if (use_c < 0) return use_c;
+  return (use_r == 1 && use_c == 1) ? 1 : 0;
+}
+
+struct FastWs {
+  float* kv; float* qdo; float4* st4; size_t total;
+  FastWs(char* base, i64 n_q, i64 n_k, i64 F) {
+    size_t off = 0;
+    kv = (float*)(base + off); off += align_up(sizeof(float) * (size_t)(n_k * 2 * F));
+    qdo = (float*)(base + off); off += align_up(sizeof(float) * (size_t)(n_q * 2 * F));
+    st4 = (float4*)(base + off); off += align_up(sizeof(float4) * (size_t)n_q);
+    total = off;
+  }
+};
+
+// E-sized intermediates of the composed path: n_arrays of n_edges*h values + the softmax scratch
+struct SlowWs {
+  char* arr[4]; char* soft; size_t total;
+  SlowWs(char* base, int n_arrays, size_t es, i64 E, i64 h, i64 soft_rows) {
+    size_t off = 0;
+    for (int i = 0; i < 4; ++i) {
+      arr[i] = base + off;
+      if (i < n_arrays) off += align_up(es * (size_t)(E * h));
+    }
+    soft = base + off; off += align_up(es * (size_t)(2 * soft_rows * h));
+    total = off;
+  }
+};
+
+inline i64 soft_rows_of(const graphop_plan* plan_r, i64 n_q) {
+  return (plan_r && plan_r->info.row_owned) ? 0 : n_q;   // general softmax path: max / sum per row
+}
+
+template <bool COL>
+int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gathered, const float* own,
+                     const float* xt, const float4* st4, float* out0, float* out1, hipStream_t st) {
+  ProfScope prof(tag, st);
+  const dim3 grid(sl.blocks), block(kFastBlock);
+  GO_DISPATCH_LNV(F, {
+    const bool off32 = n_gathered * 2 * 16LL * L * NV < (1LL << 32);
+    constexpr int BPC = COL ? kAttnBpcCol : kAttnBpcRow;
+    if (off32)
+      hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, true, BPC>), grid, block, sl.lds_bytes, st,
+                         sl.view, own, xt, st4, out0, out1);
+    else
+      hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, false, BPC>), grid, block, sl.lds_bytes, st,
+                         sl.view, own, xt, st4, out0, out1);
+  });
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+}  // namespace
+}  // namespace graphop
+
+using namespace graphop;
+
+extern "C" {
+
+int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, int64_t n_q,
+                                      int64_t n_k, int64_t h, int64_t d,
+                                      const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
+                                      void* stream, int64_t* bytes_out) {
+  const char* fn = "attention_workspace_bytes";
+  GO_CHECK_ARG(bytes_out != nullptr, "%s: bytes_out is NULL", fn);
+  GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
+  GO_CHECK_ARG(n_edges >= 0 && n_q >= 0 && n_k >= 0 && h >= 1 && d >= 0, "%s: negative size", fn);
+  const size_t es = esize(dtype);
+  if (!backward) {
+    *bytes_out = (int64_t)SlowWs(nullptr, 2, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
+    return GRAPHOP_OK;
+  }
+  AttnFast af;
+  const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
+                                  /*dry_run=*/true, &af);
+  if (fast < 0) return -fast;
+  if (fast == 1) *bytes_out = (int64_t)FastWs(nullptr, n_q, n_k, h * d).total;
+  else *bytes_out = (int64_t)SlowWs(nullptr, 4, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
+  return GRAPHOP_OK;
+}
+
+int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                              const int64_t* indices, const void* Q, const void* K, const void* V,
+                              void* o, void* stats, int64_t n_chunks, int64_t n_edges, int64_t n_q,
+                              int64_t n_k, int64_t h, int64_t d, void* workspace,
+                              int64_t workspace_bytes, const graphop_plan_t* plan, void* stream) {
+  const char* fn = "attention_forward";
+  GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
+  GO_CHECK_ARG(n_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 && h >= 1 && d >= 0,
+               "%s: negative size", fn);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = esize(dtype);
+  if (n_q * h > 0) {
+    GO_PTR(fn, stats);
+    GO_HIP(zero_async(stats, es * (size_t)(n_q * h * 2), st));   // rows without edges: (0, 0)
+  }
+  const graphop_plan* pm = plan_matches_full(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                                             (const i64*)indices, n_chunks, n_edges) ? plan : nullptr;
+  const i64 soft_rows = soft_rows_of(pm, n_q);
+  SlowWs ws((char*)workspace, 2, es, n_edges, h, soft_rows);
+  GO_CHECK_ARG(n_edges * h == 0 || (workspace != nullptr && (size_t)workspace_bytes >= ws.total),
+               "%s: workspace of %lld bytes needed (graphop_attention_workspace_bytes), got %lld", fn,
+               (long long)ws.total, (long long)workspace_bytes);
+  void* s = ws.arr[0];
+  void* a = ws.arr[1];
+  GO_TRY(graphop_maskedmm_csr_forward(dtype, row, indptr, eid, indices, Q, K, s, n_chunks, n_edges, n_q,
+                                      n_k, h, d, pm, stream));
+  if (n_edges * h > 0)
+    GO_TRY(softmax_forward_stats(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, s, a,
+                                 n_chunks, n_edges, h, soft_rows ? ws.soft : nullptr, soft_rows, pm, st,
+                                 stats));
+  return graphop_vector_spmm_forward(dtype, row, indptr, eid, indices, a, V, o, n_chunks, n_edges, n_k,
+                                     n_q, h, d, pm, stream);
+}
+
+int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
+                               const int64_t* eid_r, const int64_t* indices_r, const int64_t* col,
+                               const int64_t* indptr_c, const int64_t* eid_c, const int64_t* indices_c,
+                               const void* Q, const void* K, const void* V, const void* o,
+                               const void* stats, const void* dO, void* dQ, void* dK, void* dV,
+                               int64_t n_row_chunks, int64_t n_col_chunks, int64_t n_edges,
+                               int64_t n_q, int64_t n_k, int64_t h, int64_t d, void* workspace,
+                               int64_t workspace_bytes, const graphop_plan_t* plan_r,
+                               const graphop_plan_t* plan_c, void* stream) {
+  const char* fn = "attention_backward";
+  GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
+  GO_CHECK_ARG(n_row_chunks >= 0 && n_col_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 &&
+               h >= 1 && d >= 0, "%s: negative size", fn);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = esize(dtype);
+  const graphop_plan* pr = plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r,
+                                             (const i64*)indices_r, n_row_chunks, n_edges) ? plan_r : nullptr;
+  const graphop_plan* pc = plan_matches_full(plan_c, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
+                                             (const i64*)indices_c, n_col_chunks, n_edges) ? plan_c : nullptr;
+  AttnFast af;
+  const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, pr, pc, st, /*dry_run=*/false, &af);
+  if (fast < 0) return -fast;
+  if (fast == 1) {
+    const i64 F = d;   // h == 1
+    FastWs ws((char*)workspace, n_q, n_k, F);
+    GO_CHECK_ARG(workspace != nullptr && (size_t)workspace_bytes >= ws.total,
+                 "%s: workspace of %lld bytes needed (graphop_attention_workspace_bytes), got %lld", fn,
+                 (long long)ws.total, (long long)workspace_bytes);
+    GO_PTR(fn, Q); GO_PTR(fn, K); GO_PTR(fn, V); GO_PTR(fn, o); GO_PTR(fn, stats); GO_PTR(fn, dO);
+    GO_PTR(fn, dQ); GO_PTR(fn, dK); GO_PTR(fn, dV);
+    GO_HIP(zero_async(dQ, sizeof(float) * (size_t)(n_q * F), st));
+    GO_HIP(zero_async(dK, sizeof(float) * (size_t)(n_k * F), st));
+    GO_HIP(zero_async(dV, sizeof(float) * (size_t)(n_k * F), st));
+    {
+      ProfScope prof("attn_pack", st);
+      GO_DISPATCH_LNV((int)F, {
+        constexpr int RPB = kFastBlock / L;
+        hipLaunchKernelGGL((k_attn_pack<L, NV, false>), dim3((unsigned)ceil_div(n_k, RPB)), dim3(kFastBlock),
+                           0, st, (const float*)K, (const float*)V, ws.kv, n_k, (const float*)nullptr,
+                           (const float*)nullptr, (float4*)nullptr);
+        hipLaunchKernelGGL((k_attn_pack<L, NV, true>), dim3((unsigned)ceil_div(n_q, RPB)), dim3(kFastBlock),
+                           0, st, (const float*)Q, (const float*)dO, ws.qdo, n_q, (const float*)o,
+                           (const float*)stats, ws.st4);
+      });
+      GO_LAUNCH_CHECK();
+    }
+    GO_TRY(launch_attn_pass<false>("attn_bwd_row", af.r, (int)F, n_k, ws.qdo, ws.kv, ws.st4, (float*)dQ,
+                                   nullptr, st));
+    GO_TRY(launch_attn_pass<true>("attn_bwd_col", af.c, (int)F, n_q, ws.kv, ws.qdo, ws.st4, (float*)dK,
+                                  (float*)dV, st));
+    return GRAPHOP_OK;
+  }
+  // composition of the unfused entry points: recompute s and a, then the three backward ops
+  const i64 soft_rows = soft_rows_of(pr, n_q);
+  SlowWs ws((char*)workspace, 4, es, n_edges, h, soft_rows);
+  GO_CHECK_ARG(n_edges * h == 0 || (workspace != nullptr && (size_t)workspace_bytes >= ws.total),
+               "%s: workspace of %lld bytes needed (graphop_attention_workspace_bytes), got %lld", fn,
+               (long long)ws.total, (long long)workspace_bytes);
+  void* s = ws.arr[0];
+  void* a = ws.arr[1];
+  void* da = ws.arr[2];
+  void* ds = ws.arr[3];
+  GO_TRY(graphop_maskedmm_csr_forward(dtype, row, indptr_r, eid_r, indices_r, Q, K, s, n_row_chunks,
+                                      n_edges, n_q, n_k, h, d, pr, stream));
+  GO_TRY(graphop_sparse_softmax_forward(dtype, row, indptr_r, eid_r, s, a, n_row_chunks, n_edges, h,
+                                        soft_rows ? ws.soft : nullptr, soft_rows, pr, stream));
+  GO_TRY(graphop_vector_spmm_backward(dtype, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
+                                      indices_c, a, dO, V, da, dV, n_row_chunks, n_col_chunks, n_edges,
+                                      n_k, n_q, h, d, pr, pc, stream));
+  GO_TRY(graphop_sparse_softmax_backward(dtype, row, indptr_r, eid_r, a, da, ds, n_row_chunks, n_edges, h,
+                                         soft_rows ? ws.soft : nullptr, soft_rows, pr, stream));
+  return graphop_maskedmm_csr_backward(dtype, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
+                                       indices_c, Q, K, ds, dQ, dK, n_row_chunks, n_col_chunks, n_edges,
+                                       n_q, n_k, h, d, pr, pc, stream);
+}
+
+}  // extern "C"

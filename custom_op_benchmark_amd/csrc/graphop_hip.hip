@@ -9,8 +9,10 @@
 #include <vector>
 
 #include "common.h"
+#include "host.h"
 #include "kernels_fast.h"
 #include "kernels_block.h"
+#include "kernels_attn.h"
 #include "kernels_generic.h"
 
 namespace graphop {
@@ -31,22 +33,17 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
-struct ProfScope {  // brackets one kernel launch with two events when profiling is enabled
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  hipStream_t st;
-  const char* name;
-  ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
-    if (!g_prof_on) return;
-    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) { t0 = nullptr; return; }
-    (void)hipEventRecord(t0, st);
-  }
-  ~ProfScope() {
-    if (!t0) return;
-    (void)hipEventRecord(t1, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back({name, t0, t1});
-  }
-};
+ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
+  if (!g_prof_on) return;
+  if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) { t0 = nullptr; return; }
+  (void)hipEventRecord(t0, st);
+}
+ProfScope::~ProfScope() {
+  if (!t0) return;
+  (void)hipEventRecord(t1, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back({name, t0, t1});
+}
 
 int partition_count(const i64*, i64, i64, i64*, hipStream_t);
 int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_t);
@@ -57,64 +54,6 @@ void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
 
-namespace {
-
-struct Tuning {
-  int sddmm_cpg;  // chunks per lane-group, SDDMM-type kernels
-  int spmm_cpg;   // chunks per lane-group, SpMM-type kernels
-  int force_generic;
-  int sweep;            // use the window-sweep drivers when a plan allows it
-  int window_kb;        // target bytes of gathered table per window (must sit in a 4 MiB L2)
-  int mall_window_kb;   // window size for tables beyond the Infinity Cache
-  int max_windows;
-  int sweep_min_kb;     // tables smaller than this are L2-friendly enough for the chunk drivers
-  int sweep_bpc;        // resident blocks per CU for the sweep drivers
-  int sweep_k;          // vrows per lane group (0 = auto)
-  int vrow_t;           // vrow length cap (0 = auto from the mean row length)
-  int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
-  int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
-  int sweep_prefetch;     // touch the next window at the start of every step
-  int dense_blocks;       // use the fp32-MFMA block-dense drivers when the plan found a cover
-  int dense_min_fill;     // ... whose 32x32 tiles hold at least this many percent edges
-  int dense_detect_min_fill;  // plan creation keeps a block cover only above this fill (percent)
-  int sweep_w;            // > 0: number of column windows (overrides window_kb)
-  int spmm_window_scale;  // window-owner SpMM over identity-eid slots: windows this many times window_kb
-  int sweep_mode;         // 0: workgroups own vrows and walk the windows in step (paced sweep);
-                          // 1: XCDs own windows, waves pull (window, vrow tile) tasks (window-owner)
-  int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
-  int n_cu;
-  Tuning() {
-    sweep = env_int("GRAPHOP_SWEEP", 1);
-    window_kb = env_int("GRAPHOP_WINDOW_KB", 4096);
-    mall_window_kb = env_int("GRAPHOP_MALL_WINDOW_KB", 32768);
-    max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
-    sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 4608);
-    sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
-    sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
-    vrow_t = env_int("GRAPHOP_VROW_T", 0);
-    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
-    sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
-    transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
-    sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
-    sweep_mode = env_int("GRAPHOP_SWEEP_MODE", 1);
-    sweep_w = env_int("GRAPHOP_SWEEP_W", 0);
-    spmm_window_scale = env_int("GRAPHOP_SPMM_WINDOW_SCALE", 2);
-    dense_blocks = env_int("GRAPHOP_DENSE_BLOCKS", 1);
-    dense_min_fill = env_int("GRAPHOP_DENSE_MIN_FILL", 40);
-    dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
-    n_cu = 256;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    sddmm_cpg = env_int("GRAPHOP_SDDMM_CPG", 8);
-    spmm_cpg = env_int("GRAPHOP_SPMM_CPG", 16);
-    force_generic = env_int("GRAPHOP_FORCE_GENERIC", 0);
-    if (sddmm_cpg < 1) sddmm_cpg = 1;
-    if (spmm_cpg < 1) spmm_cpg = 1;
-  }
-};
 Tuning& tuning_mut() {
   static Tuning t;
   return t;
@@ -122,7 +61,7 @@ Tuning& tuning_mut() {
 const Tuning& tuning() { return tuning_mut(); }
 
 // Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
-inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
+hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
   unsigned char* p = (unsigned char*)ptr;
   const size_t head = (16 - ((uintptr_t)p & 15)) & 15;
@@ -142,9 +81,7 @@ inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
   return hipGetLastError();
 }
 
-inline size_t esize(int dtype) { return dtype == GRAPHOP_F64 ? 8 : 4; }
-
-inline bool pow2(i64 v) { return v > 0 && (v & (v - 1)) == 0; }
+namespace {
 
 inline unsigned blocks_for(i64 work, i64 per_block) {
   i64 b = ceil_div(work > 0 ? work : 1, per_block);
@@ -160,47 +97,22 @@ inline bool fast_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_src_rows) {
   return true;
 }
 
-#define GO_DISPATCH_LNV(F, ...)                                      \
-  switch (F) {                                                       \
-    case 16: { constexpr int L = 4, NV = 1; __VA_ARGS__; } break;    \
-    case 32: { constexpr int L = 8, NV = 1; __VA_ARGS__; } break;    \
-    case 64: { constexpr int L = 16, NV = 1; __VA_ARGS__; } break;   \
-    case 128: { constexpr int L = 32, NV = 1; __VA_ARGS__; } break;  \
-    case 256: { constexpr int L = 64, NV = 1; __VA_ARGS__; } break;  \
-    case 512: { constexpr int L = 64, NV = 2; __VA_ARGS__; } break;  \
-    case 1024: { constexpr int L = 64, NV = 4; __VA_ARGS__; } break; \
-    default: break;                                                  \
-  }
-
-inline bool plan_matches_full(const graphop_plan* p, const i64* row, const i64* indptr,
-                              const i64* eid, const i64* indices, i64 C, i64 E) {
-  return p && p->row == (const int64_t*)row && p->indptr == (const int64_t*)indptr &&
-         p->eid == (const int64_t*)eid && p->indices == (const int64_t*)indices &&
-         p->info.n_chunks == C && p->info.n_edges == E;
-}
-
-inline i64 pow2ceil(i64 v) { i64 p = 1; while (p < v) p <<= 1; return p; }
-
-struct SweepLaunch {
-  SweepView view;
-  unsigned blocks;
-  size_t lds_bytes;
-  bool window_owner;
-};
-
 // Decide whether the window-sweep driver applies and fetch / build its structure.
 // Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
-inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
-                        SweepLaunch* out, int force_windows = 0, bool accumulating = false) {
+}  // namespace
+
+int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
+                 SweepLaunch* out, int force_windows, bool accumulating, const SweepOpts* opts) {
   const Tuning& t = tuning();
   if (!t.sweep || !plan) return 0;
   const graphop_plan_info_t& pi = plan->info;
   if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
   if (!pi.eid_identity && !plan->eid32) return 0;
   if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
-  const i64 row_bytes = 16LL * L * NV;
+  const i64 row_bytes = (opts && opts->row_bytes > 0) ? opts->row_bytes : 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
   if (!force_windows && table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
+  if (opts && opts->require_owner && (t.sweep_mode != 1 || force_windows)) return 0;
   // Two tiers.  L2-sized windows (<= 4 MB) while a (row, window) granule still holds a few slots;
   // otherwise, for tables that do not fit the 256 MiB Infinity Cache next to the streams, 32 MB
   // windows that stay Infinity-Cache resident (HBM-rate random row gathers become Infinity-Cache-
@@ -214,6 +126,7 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   // Cache) and vrows twice as long -- measured on Reddit-shape: 2.25 ms at W=8 vs 2.46 at W=16.
   int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
                 t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
+  if (opts && opts->window_scale > 0) coarse = opts->window_scale;
   i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
   if (!force_windows && t.sweep_w > 0) W = t.sweep_w;   // experiments: window count given directly
   if (!force_windows && !windows_ok(W)) {
@@ -227,13 +140,15 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   if (W < 2 || W > t.max_windows) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
   int K = t.sweep_k > 0 ? t.sweep_k : (8 / NV > 0 ? 8 / NV : 1);
+  if (opts && opts->K > 0) K = opts->K;
   // passes that gather their per-slot scalars through eid (the column-major ones) run with half
   // the vrows per lane group: the columns in flight on an XCD then span half as many ids, and more
   // of the scalar lines they share are still in L2 (Reddit-shape: 3.27 -> 3.06 ms per pass)
-  if (t.sweep_k <= 0 && !pi.eid_identity && t.sweep_mode == 1 && !force_windows && K > 1) K /= 2;
+  if (t.sweep_k <= 0 && !(opts && opts->K > 0) && !pi.eid_identity && t.sweep_mode == 1 && !force_windows && K > 1) K /= 2;
   if (K > L) K = L;
   const int gpb = kFastBlock / L;
-  const int bpc = t.sweep_bpc < 1 ? 1 : (t.sweep_bpc > kSweepBlocksPerCu ? kSweepBlocksPerCu : t.sweep_bpc);
+  const int bpc_req = (opts && opts->bpc > 0) ? opts->bpc : t.sweep_bpc;
+  const int bpc = bpc_req < 1 ? 1 : (bpc_req > kSweepBlocksPerCu ? kSweepBlocksPerCu : bpc_req);
   int T = t.vrow_t;
   if (T <= 0) {
     // vrow length cap: long rows are cut so that one round of the resident grid gets a vrow per
@@ -260,13 +175,14 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
     out->view.vr_row = sw->vr_row;
     out->view.idx32 = plan->idx32;
     out->view.eid32 = plan->eid32;
-    out->view.sync = plan_take_queue(const_cast<graphop_plan*>(plan), sw);
+    const bool dry = opts && opts->dry_run;
+    out->view.sync = dry ? nullptr : plan_take_queue(const_cast<graphop_plan*>(plan), sw);
     out->view.V = sw->V;
     out->view.W = sw->W;
     out->view.K = K;
     out->view.win_bytes = win_cols * row_bytes;
     out->view.table_bytes = table_bytes;
-    if (zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
+    if (!dry && zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
     i64 nb = (i64)t.n_cu * bpc;
     const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
     if (nb > need) nb = need;
@@ -309,6 +225,8 @@ inline int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int N
   out->lds_bytes = (size_t)gpb * K * row_bytes;
   return 1;
 }
+
+namespace {
 
 template <int L, int NV>
 int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
@@ -362,7 +280,7 @@ inline int transpose_scalars(const graphop_plan* plan, const graphop_plan* other
   const int use = choose_sweep(other, n_other_cols, 16, 1, st, &sl, (int)Ws);
   if (use != 1) return use;
   ProfScope prof("transpose_scalars", st);
-  hipLaunchKernelGGL(k_scatter_scalars_sweep, dim3(sl.blocks), dim3(kFastBlock), 0, st, sl.view,
+  hipLaunchKernelGGL((k_scatter_scalars_sweep<16>), dim3(sl.blocks), dim3(kFastBlock), 0, st, sl.view,
                      (const int*)p->inv32, w, p->scalar_scratch);
   *w_slot = p->scalar_scratch;
   return 1;
@@ -601,7 +519,7 @@ inline int seg_group_width(i64 items_per_seg, i64 h) {
 
 template <typename T, bool BWD>
 int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid, const T* in0,
-                       const T* in1, T* out, i64 h, hipStream_t st) {
+                       const T* in1, T* out, i64 h, hipStream_t st, T* stats = nullptr) {
   const i64 S = p->info.n_segments;
   if (S == 0) return GRAPHOP_OK;
   ProfScope prof(BWD ? "softmax_bwd" : "softmax_fwd", st);
@@ -615,7 +533,7 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
   if constexpr (!BWD)                                                                            \
     hipLaunchKernelGGL((k_softmax_fwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
                        (const i64*)p->seg_chunk, indptr, eid, in0, out, S, (int)h, long_len,     \
-                       (const int*)p->long_segs, n_long);                                        \
+                       (const int*)p->long_segs, n_long, (const i64*)p->row, stats);             \
   else                                                                                           \
     hipLaunchKernelGGL((k_softmax_bwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
                        (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, (int)h, long_len, \
@@ -632,7 +550,8 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
   } else {
     const unsigned nb = blocks_for(S, kFastBlock / kWave);
     hipLaunchKernelGGL((k_softmax_seg_anyh<T, BWD>), dim3(nb), dim3(kFastBlock), 0, st,
-                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, h);
+                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, h, (const i64*)p->row,
+                       BWD ? (T*)nullptr : stats);
   }
   GO_LAUNCH_CHECK();
   return GRAPHOP_OK;
@@ -640,12 +559,13 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
 
 template <typename T>
 int softmax_forward_t(const i64* row, const i64* indptr, const i64* eid, const T* x, T* y, i64 C,
-                      i64 E, i64 h, T* ws, i64 ws_rows, const graphop_plan* plan, hipStream_t st) {
+                      i64 E, i64 h, T* ws, i64 ws_rows, const graphop_plan* plan, hipStream_t st,
+                      T* stats = nullptr) {
   const bool owned = plan_matches(plan, row, indptr, eid, C, E) && plan->info.row_owned;
   const bool covered = owned && plan->info.full_coverage && plan->info.eid_identity;
   if (!covered && E * h > 0) GO_HIP(zero_async(y, sizeof(T) * (size_t)(E * h), st));
   if (C == 0) return GRAPHOP_OK;
-  if (owned) return launch_softmax_seg<T, false>(plan, indptr, eid, x, (const T*)nullptr, y, h, st);
+  if (owned) return launch_softmax_seg<T, false>(plan, indptr, eid, x, (const T*)nullptr, y, h, st, stats);
   GO_CHECK_ARG(ws != nullptr && ws_rows > 0,
                "sparse_softmax_forward: the general (plan-less) path needs a workspace of "
                "2*workspace_rows*h values with workspace_rows > max(row)");
@@ -662,6 +582,9 @@ int softmax_forward_t(const i64* row, const i64* indptr, const i64* eid, const T
                      eid, x, (const T*)max_val, sum, y, C, h);
   hipLaunchKernelGGL((k_softmax_norm<T>), dim3(nb), dim3(kGenericBlock), 0, st, row, indptr, eid,
                      (const T*)sum, y, C, h);
+  if (stats)   // row statistics for the fused attention backward, rows [0, ws_rows)
+    hipLaunchKernelGGL((k_attn_stats_from_ws<T>), dim3(fb), dim3(256), 0, st, (const T*)max_val,
+                       (const T*)sum, stats, ws_rows * h);
   GO_LAUNCH_CHECK();
   return GRAPHOP_OK;
 }
@@ -696,14 +619,34 @@ inline int check_common(const char* fn, int dtype, i64 C, i64 E, i64 h, i64 d) {
   return GRAPHOP_OK;
 }
 
-#define GO_PTR(fn, p) GO_CHECK_ARG((p) != nullptr, "%s: " #p " is NULL", fn)
-#define GO_TRY(expr)                     \
-  do {                                   \
-    int _rc = (expr);                    \
-    if (_rc != GRAPHOP_OK) return _rc;   \
-  } while (0)
+// Row ids address the row-side operand / output: with a plan the largest one is known, so an
+// operand with too few rows is an error here instead of an out-of-bounds access on the device.
+inline int check_rows(const char* fn, const char* what, const graphop_plan* plan, i64 n_rows) {
+  GO_CHECK_ARG(!plan || plan->info.max_row < n_rows,
+               "%s: row id %lld but %s has only %lld rows", fn, plan ? (long long)plan->info.max_row : 0LL,
+               what, (long long)n_rows);
+  return GRAPHOP_OK;
+}
+inline int check_cols(const char* fn, const char* what, const graphop_plan* plan, i64 n_rows) {
+  GO_CHECK_ARG(!plan || plan->info.max_index < n_rows,
+               "%s: neighbour id %lld but %s has only %lld rows", fn,
+               plan ? (long long)plan->info.max_index : 0LL, what, (long long)n_rows);
+  return GRAPHOP_OK;
+}
+
 
 }  // namespace
+
+// sparse_softmax_forward that also leaves the row statistics (max, 1 / sum) behind (attention.hip)
+int softmax_forward_stats(int dtype, const i64* row, const i64* indptr, const i64* eid, const void* x,
+                          void* y, i64 C, i64 E, i64 h, void* ws, i64 ws_rows,
+                          const graphop_plan* plan, hipStream_t st, void* stats) {
+  if (dtype == GRAPHOP_F32)
+    return softmax_forward_t<float>(row, indptr, eid, (const float*)x, (float*)y, C, E, h, (float*)ws,
+                                    ws_rows, plan, st, (float*)stats);
+  return softmax_forward_t<double>(row, indptr, eid, (const double*)x, (double*)y, C, E, h, (double*)ws,
+                                   ws_rows, plan, st, (double*)stats);
+}
 }  // namespace graphop
 
 using namespace graphop;
@@ -724,7 +667,8 @@ int graphop_tune(const char* key, int value) {
       {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch},
       {"sweep_mode", &t.sweep_mode}, {"sweep_w", &t.sweep_w}, {"spmm_window_scale", &t.spmm_window_scale}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
-      {"transpose_scalars", &t.transpose_scalars}};
+      {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
+      {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
@@ -859,7 +803,11 @@ int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* i
   if (!covered) GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_edges * h), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, A); GO_PTR(fn, B);
-  (void)n_a;
+  {
+    const graphop_plan* pm = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid, n_chunks, n_edges) ? plan : nullptr;
+    GO_TRY(check_rows(fn, "A", pm, n_a));
+    GO_TRY(check_cols(fn, "B", pm && pm->indices == indices ? pm : nullptr, n_b));
+  }
   return launch_sddmm<false>("sddmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                              (const i64*)indices, A, B, y, n_chunks, n_edges, n_b, h, d, plan, st);
 }
@@ -878,6 +826,12 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   GO_CHECK_ARG(n_col_chunks >= 0 && n_a >= 0 && n_b >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
+  {
+    const graphop_plan* pr = plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r, n_row_chunks, n_edges) ? plan_r : nullptr;
+    const graphop_plan* pc = plan_matches_full(plan_c, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c, n_col_chunks, n_edges) ? plan_c : nullptr;
+    GO_TRY(check_rows(fn, "A / dA", pr, n_a)); GO_TRY(check_cols(fn, "B", pr, n_b));
+    GO_TRY(check_rows(fn, "B / dB", pc, n_b)); GO_TRY(check_cols(fn, "A", pc, n_a));
+  }
   if (n_a * h * d > 0) {
     GO_PTR(fn, dA);
     if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r,
@@ -956,6 +910,10 @@ int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* in
   GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
   GO_CHECK_ARG(n_x >= 0 && n_y >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const graphop_plan* pm = plan_matches_full(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices, n_chunks, n_edges) ? plan : nullptr;
+    GO_TRY(check_rows(fn, "y", pm, n_y)); GO_TRY(check_cols(fn, "x", pm, n_x));
+  }
   if (n_y * h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
   if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices,
@@ -980,6 +938,12 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
   GO_CHECK_ARG(n_col_chunks >= 0 && n_x >= 0 && n_dy >= 0, "%s: negative size", fn);
   hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
+  {
+    const graphop_plan* pr = plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices, n_row_chunks, n_edges) ? plan_r : nullptr;
+    const graphop_plan* pc = plan_matches_full(plan_c, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t, n_col_chunks, n_edges) ? plan_c : nullptr;
+    GO_TRY(check_rows(fn, "dy", pr, n_dy)); GO_TRY(check_cols(fn, "x", pr, n_x));
+    GO_TRY(check_rows(fn, "x / dx", pc, n_x)); GO_TRY(check_cols(fn, "dy", pc, n_dy));
+  }
   if (n_edges * h > 0) {
     GO_PTR(fn, dedata);
     const bool covered = plan_matches(plan_r, (const i64*)row, (const i64*)indptr, (const i64*)eid,
@@ -1020,7 +984,7 @@ int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* 
   const char* fn = "node_mul_edge_forward";
   GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
   hipStream_t st = (hipStream_t)stream;
-  (void)n_a;
+  GO_TRY(check_rows(fn, "A", plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid, n_chunks, n_edges) ? plan : nullptr, n_a));
   if (n_edges * h == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
   const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
@@ -1057,6 +1021,7 @@ int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t*
   const bool covered = plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                                     n_chunks, n_edges) &&
                        plan->info.full_coverage && plan->info.eid_identity && plan->info.indptr_monotone;
+  GO_TRY(check_rows(fn, "A / dA", plan_matches(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid, n_chunks, n_edges) ? plan : nullptr, n_a));
   if (n_a * h * d > 0) { GO_PTR(fn, dA); GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st)); }
   if (n_edges * d > 0) {   // every edge row is written when the chunks cover all slots: skip the E*d zero-fill
     GO_PTR(fn, dB);

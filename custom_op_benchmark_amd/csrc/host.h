@@ -1,0 +1,152 @@
+// Host-side helpers shared by the translation units of libgraphop_hip (graphop_hip.hip defines
+// them; attention.hip uses them).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+namespace graphop {
+
+// brackets one kernel launch with two hipEvents when profiling is enabled (graphop_profile_enable)
+struct ProfScope {
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipStream_t st;
+  const char* name;
+  ProfScope(const char* n, hipStream_t s);
+  ~ProfScope();
+};
+
+struct Tuning {
+  int sddmm_cpg;  // chunks per lane-group, SDDMM-type kernels
+  int spmm_cpg;   // chunks per lane-group, SpMM-type kernels
+  int force_generic;
+  int sweep;            // use the window-sweep drivers when a plan allows it
+  int window_kb;        // target bytes of gathered table per window (must sit in a 4 MiB L2)
+  int mall_window_kb;   // window size for tables beyond the Infinity Cache
+  int max_windows;
+  int sweep_min_kb;     // tables smaller than this are L2-friendly enough for the chunk drivers
+  int sweep_bpc;        // resident blocks per CU for the sweep drivers
+  int sweep_k;          // vrows per lane group (0 = auto)
+  int vrow_t;           // vrow length cap (0 = auto from the mean row length)
+  int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
+  int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
+  int sweep_prefetch;     // touch the next window at the start of every step
+  int dense_blocks;       // use the fp32-MFMA block-dense drivers when the plan found a cover
+  int dense_min_fill;     // ... whose 32x32 tiles hold at least this many percent edges
+  int dense_detect_min_fill;  // plan creation keeps a block cover only above this fill (percent)
+  int sweep_w;            // > 0: number of column windows (overrides window_kb)
+  int spmm_window_scale;  // window-owner SpMM over identity-eid slots: windows this many times window_kb
+  int sweep_mode;         // 0: workgroups own vrows and walk the windows in step (paced sweep);
+                          // 1: XCDs own windows, waves pull (window, vrow tile) tasks (window-owner)
+  int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
+  int attn_fused;         // attention_forward/backward: use the fused window kernels when they apply
+  int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
+  int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
+  int attn_bpc;           // resident workgroups per CU of the fused kernels
+  int n_cu;
+  Tuning() {
+    sweep = env_int("GRAPHOP_SWEEP", 1);
+    window_kb = env_int("GRAPHOP_WINDOW_KB", 4096);
+    mall_window_kb = env_int("GRAPHOP_MALL_WINDOW_KB", 32768);
+    max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
+    sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 4608);
+    sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
+    sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
+    vrow_t = env_int("GRAPHOP_VROW_T", 0);
+    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
+    sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
+    transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
+    sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
+    sweep_mode = env_int("GRAPHOP_SWEEP_MODE", 1);
+    sweep_w = env_int("GRAPHOP_SWEEP_W", 0);
+    spmm_window_scale = env_int("GRAPHOP_SPMM_WINDOW_SCALE", 2);
+    dense_blocks = env_int("GRAPHOP_DENSE_BLOCKS", 1);
+    dense_min_fill = env_int("GRAPHOP_DENSE_MIN_FILL", 40);
+    dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
+    attn_fused = env_int("GRAPHOP_ATTN_FUSED", 1);
+    attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
+    attn_k = env_int("GRAPHOP_ATTN_K", 0);
+    attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
+    n_cu = 256;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    sddmm_cpg = env_int("GRAPHOP_SDDMM_CPG", 8);
+    spmm_cpg = env_int("GRAPHOP_SPMM_CPG", 16);
+    force_generic = env_int("GRAPHOP_FORCE_GENERIC", 0);
+    if (sddmm_cpg < 1) sddmm_cpg = 1;
+    if (spmm_cpg < 1) spmm_cpg = 1;
+  }
+};
+Tuning& tuning_mut();
+const Tuning& tuning();
+
+// Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
+hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st);
+
+struct SweepView;   // kernels_fast.h
+}  // namespace graphop
+
+#include "kernels_fast.h"
+
+namespace graphop {
+
+struct SweepLaunch {
+  SweepView view;
+  unsigned blocks;
+  size_t lds_bytes;
+  bool window_owner;
+};
+
+// Overrides for kernels whose gathered rows / per-vrow LDS rows are not one F-float row
+// (the fused attention kernels gather two packed rows per slot).
+struct SweepOpts {
+  i64 row_bytes = 0;      // bytes per gathered table row (0 = 16*L*NV)
+  int K = 0;              // vrows per lane group (0 = auto)
+  int window_scale = 0;   // > 0: windows of this many times window_kb, vrows as many times longer
+  int bpc = 0;            // resident workgroups per CU (0 = tuning().sweep_bpc)
+  int require_owner = 0;  // 1: only the window-owner order is acceptable (return 0 otherwise)
+  int dry_run = 0;        // 1: decide and build the cached structure only (no task queue is taken)
+};
+
+// Decide whether the window-sweep driver applies and fetch / build its structure.
+// Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
+int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
+                 SweepLaunch* out, int force_windows = 0, bool accumulating = false,
+                 const SweepOpts* opts = nullptr);
+
+int softmax_forward_stats(int dtype, const i64* row, const i64* indptr, const i64* eid, const void* x,
+                          void* y, i64 C, i64 E, i64 h, void* ws, i64 ws_rows,
+                          const graphop_plan* plan, hipStream_t st, void* stats);
+
+inline size_t esize(int dtype) { return dtype == GRAPHOP_F64 ? 8 : 4; }
+inline bool pow2(i64 v) { return v > 0 && (v & (v - 1)) == 0; }
+inline i64 pow2ceil(i64 v) { i64 p = 1; while (p < v) p <<= 1; return p; }
+
+inline bool plan_matches_full(const graphop_plan* p, const i64* row, const i64* indptr,
+                              const i64* eid, const i64* indices, i64 C, i64 E) {
+  return p && p->row == (const int64_t*)row && p->indptr == (const int64_t*)indptr &&
+         p->eid == (const int64_t*)eid && p->indices == (const int64_t*)indices &&
+         p->info.n_chunks == C && p->info.n_edges == E;
+}
+
+#define GO_DISPATCH_LNV(F, ...)                                      \
+  switch (F) {                                                       \
+    case 16: { constexpr int L = 4, NV = 1; __VA_ARGS__; } break;    \
+    case 32: { constexpr int L = 8, NV = 1; __VA_ARGS__; } break;    \
+    case 64: { constexpr int L = 16, NV = 1; __VA_ARGS__; } break;   \
+    case 128: { constexpr int L = 32, NV = 1; __VA_ARGS__; } break;  \
+    case 256: { constexpr int L = 64, NV = 1; __VA_ARGS__; } break;  \
+    case 512: { constexpr int L = 64, NV = 2; __VA_ARGS__; } break;  \
+    case 1024: { constexpr int L = 64, NV = 4; __VA_ARGS__; } break; \
+    default: break;                                                  \
+  }
+
+#define GO_PTR(fn, p) GO_CHECK_ARG((p) != nullptr, "%s: " #p " is NULL", fn)
+#define GO_TRY(expr)                     \
+  do {                                   \
+    int _rc = (expr);                    \
+    if (_rc != GRAPHOP_OK) return _rc;   \
+  } while (0)
+
+}  // namespace graphop

@@ -1115,9 +1115,9 @@ __global__ __launch_bounds__(kFastBlock) void k_nme_bwd_f32(
 // writes of one (XCD vrow range, column window) step land in a few MB of the column-major array
 // and are combined in that XCD's L2 before they leave).  The column-major pass then reads its
 // weights sequentially instead of gathering 4 bytes per slot.
+template <int L>   // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(kFastBlock) void k_scatter_scalars_sweep(
     SweepView s, const int* __restrict__ inv, const float* __restrict__ in, float* __restrict__ out) {
-  constexpr int L = 16;
   constexpr int GPB = kFastBlock / L;
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
@@ -1181,7 +1181,7 @@ template <typename T, int G, bool EID_ID>
 __device__ __forceinline__ void softmax_fwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
-    i64 long_len, i64 block) {
+    i64 long_len, i64 block, const i64* __restrict__ row, T* __restrict__ stats) {
   constexpr int R = kSoftmaxCacheFwd;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
@@ -1226,6 +1226,10 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
       const i64 q = l + (i64)r * G;
       if (q < items) y[offs(q)] = v[r] / sum;
     }
+    if (stats && l < h) {   // row statistics for the fused attention backward: (max, 1 / sum)
+      const i64 o = (row[seg_chunk[s]] * h + l) * 2;
+      stats[o] = m; stats[o + 1] = (T)1 / sum;
+    }
     return;
   }
 
@@ -1254,6 +1258,10 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
     const i64 k = e0 + q / h;
     const i64 o = (EID_ID ? k : eid[k]) * h + t;
     y[o] = exp_t(x[o] - m) / sum;
+  }
+  if (stats && l < h) {
+    const i64 o = (row[seg_chunk[s]] * h + l) * 2;
+    stats[o] = m; stats[o + 1] = (T)1 / sum;
   }
 }
 
@@ -1371,7 +1379,8 @@ template <typename T, bool BWD, bool EID_ID>
 __device__ __forceinline__ void softmax_long_body(
     const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk,
     const i64* __restrict__ indptr, const i64* __restrict__ eid, const T* __restrict__ in0,
-    const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s, i64 long_len) {
+    const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s, i64 long_len,
+    const i64* __restrict__ row = nullptr, T* __restrict__ stats = nullptr) {
   constexpr int RB = kBlockCache;
   const i64 s = long_segs[blockIdx.x];
   const i64 e0 = indptr[seg_chunk[s]];
@@ -1433,6 +1442,10 @@ __device__ __forceinline__ void softmax_long_body(
           else out[offs(q)] = v[r] / sum;
         }
       }
+      if (stats && tid < h) {
+        const i64 o = (row[seg_chunk[s]] * h + tid) * 2;
+        stats[o] = m; stats[o + 1] = (T)1 / sum;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < RB; ++r) sum += u[r] * v[r];
@@ -1465,6 +1478,12 @@ __device__ __forceinline__ void softmax_long_body(
     if constexpr (!BWD) out[o] = exp_t(in0[o] - m) / sum;
     else { const T yy = in0[o]; out[o] = in1[o] * yy - sum * yy; }
   }
+  if constexpr (!BWD) {
+    if (stats && tid < h) {
+      const i64 o = (row[seg_chunk[s]] * h + tid) * 2;
+      stats[o] = m; stats[o + 1] = (T)1 / sum;
+    }
+  }
 }
 
 // One launch: workgroups [0, n_long) take the hub rows (dispatched first, so their long serial
@@ -1473,15 +1492,16 @@ template <typename T, int G, bool EID_ID>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
-    i64 long_len, const int* __restrict__ long_segs, int n_long) {
+    i64 long_len, const int* __restrict__ long_segs, int n_long, const i64* __restrict__ row,
+    T* __restrict__ stats) {
   __shared__ T sh_m[kFastBlock];
   __shared__ T sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
     softmax_long_body<T, false, EID_ID>(long_segs, seg_chunk, indptr, eid, x, (const T*)nullptr, y, h,
-                                        sh_m, sh_s, long_len);
+                                        sh_m, sh_s, long_len, row, stats);
   else
     softmax_fwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, x, y, n_seg, h, long_len,
-                                       (i64)blockIdx.x - n_long);
+                                       (i64)blockIdx.x - n_long, row, stats);
 }
 
 template <typename T, int G, bool EID_ID>
@@ -1504,7 +1524,8 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_seg_anyh(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ in0 /* x | y */,
-    const T* __restrict__ in1 /* - | dy */, T* __restrict__ out, i64 n_seg, i64 h) {
+    const T* __restrict__ in1 /* - | dy */, T* __restrict__ out, i64 n_seg, i64 h,
+    const i64* __restrict__ row = nullptr, T* __restrict__ stats = nullptr) {
   const int lane = threadIdx.x & 63;
   const i64 s = (i64)blockIdx.x * (kFastBlock / kWave) + (threadIdx.x >> 6);
   if (s >= n_seg) return;
@@ -1527,6 +1548,10 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_seg_anyh(
       for (i64 k = e0 + lane; k < e1; k += kWave) {
         const i64 o = eid[k] * h + t;
         out[o] = exp_t(in0[o] - m) / sum;
+      }
+      if (stats && lane == 0) {
+        const i64 o = (row[seg_chunk[s]] * h + t) * 2;
+        stats[o] = m; stats[o + 1] = (T)1 / sum;
       }
     } else {
       T g = 0;

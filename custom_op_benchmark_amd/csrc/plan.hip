@@ -165,9 +165,13 @@ __global__ void k_plan_sorted_ids(const i64* __restrict__ row, const i64* __rest
   for (; c < n_chunks; c += stride) {
     const i64 a = indptr[c], b = indptr[c + 1];
     for (i64 k = a; k + 1 < b; ++k) bad += indices[k] > indices[k + 1];
-    // a row's chunks are adjacent and contiguous in slot space (row_owned): check the seam
-    if (b > a && c + 1 < n_chunks && row[c + 1] == row[c] && indptr[c + 2] > b)
-      bad += indices[b - 1] > indices[b];
+    // a row's chunks are adjacent and contiguous in slot space (row_owned): check the seam with
+    // the next NON-EMPTY chunk of the same row (hand-built layouts may interleave empty chunks)
+    if (b > a) {
+      i64 c2 = c + 1;
+      while (c2 < n_chunks && row[c2] == row[c] && indptr[c2 + 1] <= b) ++c2;
+      if (c2 < n_chunks && row[c2] == row[c]) bad += indices[b - 1] > indices[b];
+    }
   }
   if (bad) atomicAdd((unsigned long long*)&st->unsorted_ids, (unsigned long long)bad);
 }
@@ -250,6 +254,7 @@ __global__ void k_blk_same(const i64* __restrict__ seg_chunk, const i64* __restr
     if (s == S) break;
     seg_row[s] = (int32_t)row[seg_chunk[s]];
     unsigned char eq = 0;
+    if (indptr[seg_chunk[s + 1]] == e0) atomicAdd(n_same + 1, 1ULL);   // empty segment: no cover (the block kernels index slot n-1)
     if (s > 0) {
       const i64 len = indptr[seg_chunk[s + 1]] - e0;
       const i64 p0 = indptr[seg_chunk[s - 1]];
@@ -448,8 +453,8 @@ int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
   DevBuf same, cnt;
   int32_t *seg_e0 = nullptr, *seg_row = nullptr;
   GO_HIP(hipMalloc(&same.p, (size_t)S));
-  GO_HIP(hipMalloc(&cnt.p, sizeof(unsigned long long)));
-  GO_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), st));
+  GO_HIP(hipMalloc(&cnt.p, 2 * sizeof(unsigned long long)));   // [0] segments equal to their predecessor, [1] empty segments
+  GO_HIP(hipMemsetAsync(cnt.p, 0, 2 * sizeof(unsigned long long), st));
   if (hipMalloc((void**)&seg_e0, sizeof(int32_t) * (size_t)(S + 1)) != hipSuccess ||
       hipMalloc((void**)&seg_row, sizeof(int32_t) * (size_t)S) != hipSuccess) {
     (void)hipFree(seg_e0); (void)hipFree(seg_row);
@@ -459,10 +464,12 @@ int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
                      (const i64*)p->seg_chunk, (const i64*)p->indptr, (const i64*)p->row,
                      (const int32_t*)p->idx32, S, (unsigned char*)same.p, seg_e0, seg_row,
                      (unsigned long long*)cnt.p);
-  unsigned long long n_same = 0;
+  unsigned long long counts[2] = {0, 0};
   bool keep = hipGetLastError() == hipSuccess &&
-              hipMemcpyAsync(&n_same, cnt.p, sizeof(n_same), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(counts, cnt.p, sizeof(counts), hipMemcpyDeviceToHost, st) == hipSuccess &&
               hipStreamSynchronize(st) == hipSuccess;
+  const unsigned long long n_same = counts[0];
+  if (counts[1] != 0) keep = false;
   // every segment that differs from its predecessor opens a block: an upper bound on the fill
   if (keep && (double)E / (1024.0 * (double)(S - (i64)n_same)) * 100.0 < min_fill) keep = false;
   std::vector<int32_t> blk;

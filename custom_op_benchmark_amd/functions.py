@@ -75,6 +75,35 @@ class VectorSPMM(Function):
         return None, None, None, None, None, None, None, None, dedata, dx
 
 
+class FusedAttention(Function):
+    """o = VectorSPMM(SparseSoftmax(MaskedMMCSR(Q, K)), V) as ONE autograd node (extra op, not in the
+    reference): apply(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V).
+    Saves (Q, K, V, o, row statistics) instead of the E-sized s / a; the backward recomputes them
+    inside two fused passes."""
+
+    @staticmethod
+    def forward(ctx, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V):
+        o, stats = _ops.attention_forward(row, indptr_r, eid_r, indices_r, Q, K, V)
+        ctx.save_for_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V,
+                              o, stats)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        (row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V, o,
+         stats) = ctx.saved_tensors
+        dQ, dK, dV = _ops.attention_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
+                                             indices_c, Q, K, V, o, stats, dO)
+        return None, None, None, None, None, None, None, None, dQ, dK, dV
+
+
+def fused_attention_step(g, Q, K, V, dO):
+    """The same fwd+bwd as attention_step through the fused op; returns o."""
+    o = FusedAttention.apply(*g.csr_args(), Q, K, V)
+    o.backward(dO)
+    return o
+
+
 def attention_step(g, Q, K, V, dO):
     """One fwd+bwd of the composed hot path the headline metric times:
     s = SDDMM(Q, K); a = row-softmax(s); o = SpMM(a, V); o.backward(dO).

@@ -27,6 +27,8 @@ from ._lib import check, dtype_code, get_plan, lib, ptr, stream_of
 __all__ = ["maskedmm_csr_forward", "maskedmm_csr_backward", "node_mul_edge_forward",
            "node_mul_edge_backward", "sparse_softmax_forward", "sparse_softmax_backward",
            "vector_spmm_forward", "vector_spmm_backward"]
+# extra ops (not in the reference's module): the fused attention step, SURVEY.md 8f N2
+EXTRA_OPS = ["attention_forward", "attention_backward"]
 
 _NULL = _lib._vp(0)
 
@@ -241,6 +243,76 @@ def node_mul_edge_backward(row, indptr, eid, A, B, dy):
     return [dA, dB]
 
 
+# ---- fused attention step (extra op; the composition wrapper.py:20-30, 8-18, 44-55) ------------------
+def _workspace(like, dtype, backward, e, n_q, n_k, h, d, plan_r, plan_c):
+    import ctypes
+    nbytes = ctypes.c_int64(0)
+    check(lib().graphop_attention_workspace_bytes(
+        dtype, 1 if backward else 0, e, n_q, n_k, h, d, plan_r.handle if plan_r is not None else _NULL,
+        plan_c.handle if plan_c is not None else _NULL, stream_of(like), ctypes.byref(nbytes)))
+    return torch.empty(max(1, nbytes.value), dtype=torch.uint8, device=like.device), nbytes.value
+
+
+def attention_forward(row, indptr, eid, indices, Q, K, V):
+    """-> [o, stats]: o = vector_spmm(sparse_softmax(maskedmm_csr(Q, K)), V) over the row-major CSR,
+    without returning the E-sized s / a.  stats (n_q, h, 2) = (row max, 1 / sum exp) is what
+    attention_backward needs to recompute them."""
+    for t, n in ((row, "row"), (indptr, "indptr"), (eid, "eid"), (indices, "indices"), (Q, "Q"),
+                 (K, "K"), (V, "V")):
+        _check_input(t, n)
+    for t, n in ((row, "row"), (indptr, "indptr"), (eid, "eid"), (indices, "indices")):
+        _check_index(t, n)
+    _same_dtype(Q, K, "Q", "K")
+    _same_dtype(Q, V, "Q", "V")
+    if K.shape != V.shape or Q.shape[1:] != K.shape[1:]:
+        raise RuntimeError("attention_forward: Q (n_q,[h,]d), K and V (n_k,[h,]d) expected")
+    e, d = eid.size(0), Q.size(-1)
+    h = 1 if Q.dim() == 2 else Q.size(1)
+    n_q, n_k = Q.size(0), K.size(0)
+    o = torch.empty_like(Q)
+    stats = torch.empty((n_q, h, 2), dtype=Q.dtype, device=Q.device)
+    with torch.cuda.device(Q.device):
+        plan = _plan(row, indptr, eid, indices, n_k)
+        ws, nbytes = _workspace(Q, dtype_code(Q), False, e, n_q, n_k, h, d, plan, None)
+        check(lib().graphop_attention_forward(
+            dtype_code(Q), ptr(row), ptr(indptr), ptr(eid), ptr(indices), ptr(Q), ptr(K), ptr(V),
+            ptr(o), ptr(stats), row.size(0), e, n_q, n_k, h, d, ptr(ws), nbytes, plan.handle,
+            stream_of(Q)))
+    return [o, stats]
+
+
+def attention_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c,
+                       Q, K, V, o, stats, dO):
+    """-> [dQ, dK, dV] of the fused step for the output gradient dO."""
+    names = ("row", "indptr_r", "eid_r", "indices_r", "col", "indptr_c", "eid_c", "indices_c")
+    idx = (row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c)
+    for t, n in zip(idx + (Q, K, V, o, stats), names + ("Q", "K", "V", "o", "stats")):
+        _check_input(t, n)
+    for t, n in zip(idx, names):
+        _check_index(t, n)
+    if not isinstance(dO, torch.Tensor) or not dO.is_cuda:
+        raise RuntimeError("dO must be a CUDA tensor")
+    for t, n in ((K, "K"), (V, "V"), (o, "o"), (stats, "stats"), (dO, "dO")):
+        _same_dtype(Q, t, "Q", n)
+    dO = dO.contiguous()
+    e, d = eid_r.size(0), Q.size(-1)
+    h = 1 if Q.dim() == 2 else Q.size(1)
+    n_q, n_k = Q.size(0), K.size(0)
+    if o.shape != Q.shape or dO.shape != Q.shape or stats.numel() != n_q * h * 2:
+        raise RuntimeError("attention_backward: o, dO must match Q and stats must be (n_q, h, 2)")
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    with torch.cuda.device(Q.device):
+        plan_r = _plan(row, indptr_r, eid_r, indices_r, n_k)
+        plan_c = _plan(col, indptr_c, eid_c, indices_c, n_q)
+        ws, nbytes = _workspace(Q, dtype_code(Q), True, e, n_q, n_k, h, d, plan_r, plan_c)
+        check(lib().graphop_attention_backward(
+            dtype_code(Q), ptr(row), ptr(indptr_r), ptr(eid_r), ptr(indices_r), ptr(col),
+            ptr(indptr_c), ptr(eid_c), ptr(indices_c), ptr(Q), ptr(K), ptr(V), ptr(o), ptr(stats),
+            ptr(dO), ptr(dQ), ptr(dK), ptr(dV), row.size(0), col.size(0), e, n_q, n_k, h, d,
+            ptr(ws), nbytes, plan_r.handle, plan_c.handle, stream_of(Q)))
+    return [dQ, dK, dV]
+
+
 # ---- torch.ops.graphop.* ---------------------------------------------------------------------------
 _SCHEMAS = {
     "maskedmm_csr_forward": "(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor A, Tensor B) -> Tensor",
@@ -251,6 +323,8 @@ _SCHEMAS = {
     "sparse_softmax_backward": "(Tensor row, Tensor indptr, Tensor eid, Tensor y, Tensor dy) -> Tensor",
     "vector_spmm_forward": "(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor edata, Tensor x) -> Tensor",
     "vector_spmm_backward": "(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor col, Tensor indptr_t, Tensor eid_t, Tensor indices_t, Tensor edata, Tensor dy, Tensor x) -> Tensor[]",
+    "attention_forward": "(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor Q, Tensor K, Tensor V) -> Tensor[]",
+    "attention_backward": "(Tensor row, Tensor indptr_r, Tensor eid_r, Tensor indices_r, Tensor col, Tensor indptr_c, Tensor eid_c, Tensor indices_c, Tensor Q, Tensor K, Tensor V, Tensor o, Tensor stats, Tensor dO) -> Tensor[]",
 }
 _torch_lib = None
 

@@ -48,7 +48,7 @@ extern "C" {
 #define GRAPHOP_API
 #endif
 
-#define GRAPHOP_ABI_VERSION 2
+#define GRAPHOP_ABI_VERSION 3
 
 #define GRAPHOP_F32 0
 #define GRAPHOP_F64 1
@@ -87,7 +87,8 @@ GRAPHOP_API const char* graphop_last_error(void);
  * 0 = workgroups own rows and walk the windows in step), window_kb, mall_window_kb, max_windows,
  * sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift, sweep_min_granule, sweep_prefetch,
  * transpose_scalars, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
- * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile).  Not
+ * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile), attn_fused (0/1),
+ * attn_window_scale, attn_k, attn_bpc (fused attention kernels).  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
 
@@ -217,6 +218,37 @@ GRAPHOP_API int graphop_node_mul_edge_backward(int dtype, const int64_t* row, co
                                    const void* dy, void* dA, void* dB, int64_t n_chunks,
                                    int64_t n_edges, int64_t n_a, int64_t h, int64_t d,
                                    const graphop_plan_t* plan, void* stream);
+
+/* ---- fused attention step (EXTRA op, not one of the reference's eight) --------------------------
+ * The composition the reference harness chains by hand -- MaskedMMCSR -> SparseSoftmax -> VectorSPMM
+ * (wrapper.py:20-30, 8-18, 44-55) -- as one forward and one backward entry, so that the E-sized
+ * intermediates s, a, da, ds never leave the library:
+ *   forward : o[r]  = sum_j a[r,j] V[j],  a = row-softmax(<Q[r], K[j]>) over the row-major CSR;
+ *             stats[(r*h + k)*2 + {0,1}] = (row max m, 1 / sum exp(s - m))   (n_q, h, 2)
+ *   backward: dQ, dK, dV for a given dO, from (Q, K, V, o, stats): a and ds are recomputed per slot
+ *             (a = exp(s - m) / sum, ds = a (<dO_r, V_j> - <dO_r, o_r>)).
+ * Results equal the composition of the unfused entry points up to fp32 summation order.
+ * workspace: device scratch of graphop_attention_workspace_bytes(...) bytes (forward: s and a;
+ * backward: packed operand tables when the fused window kernels apply -- fp32, h == 1, plans with
+ * sorted rows, tables beyond the L2 -- else s, a, da, ds of the composed path). */
+GRAPHOP_API int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, int64_t n_q,
+                                      int64_t n_k, int64_t h, int64_t d,
+                                      const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
+                                      void* stream, int64_t* bytes_out);
+GRAPHOP_API int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                              const int64_t* indices, const void* Q, const void* K, const void* V,
+                              void* o, void* stats, int64_t n_chunks, int64_t n_edges, int64_t n_q,
+                              int64_t n_k, int64_t h, int64_t d, void* workspace,
+                              int64_t workspace_bytes, const graphop_plan_t* plan, void* stream);
+GRAPHOP_API int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
+                               const int64_t* eid_r, const int64_t* indices_r, const int64_t* col,
+                               const int64_t* indptr_c, const int64_t* eid_c, const int64_t* indices_c,
+                               const void* Q, const void* K, const void* V, const void* o,
+                               const void* stats, const void* dO, void* dQ, void* dK, void* dV,
+                               int64_t n_row_chunks, int64_t n_col_chunks, int64_t n_edges,
+                               int64_t n_q, int64_t n_k, int64_t h, int64_t d, void* workspace,
+                               int64_t workspace_bytes, const graphop_plan_t* plan_r,
+                               const graphop_plan_t* plan_c, void* stream);
 
 #ifdef __cplusplus
 }

@@ -231,6 +231,51 @@ def test_error_behaviour_on_gpu(dev):
         ops.vector_spmm_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, torch.rand(100, device=dev), A[:10].contiguous())
 
 
+def test_out_of_range_row_ids_raise(dev):
+    """Row ids index the row-side operand / output: an operand with too few rows is an error, not an
+    out-of-bounds atomic on the device (every op; the reference reads / writes out of bounds)."""
+    g = graphs.uniform_random_graph(20, 100, seed=2).to(dev)
+    A = torch.rand(20, 16, device=dev); short = A[:12].contiguous()
+    e = torch.rand(100, device=dev); Be = torch.rand(100, 16, device=dev)
+    a4, a8 = (g.row, g.ptr_r, g.eid_r, g.indices_r), g.csr_args()
+    with pytest.raises(RuntimeError, match="row id"):
+        ops.maskedmm_csr_forward(*a4, short, A)
+    with pytest.raises(RuntimeError, match="row id|neighbour id"):
+        ops.maskedmm_csr_backward(*a8, short, A, e)
+    with pytest.raises(RuntimeError, match="row id|neighbour id|indices"):
+        ops.maskedmm_csr_backward(*a8, A, short, e)
+    with pytest.raises(RuntimeError, match="row id"):
+        ops.node_mul_edge_forward(g.row, g.ptr_r, g.eid_r, short, Be)
+    with pytest.raises(RuntimeError, match="row id"):
+        ops.node_mul_edge_backward(g.row, g.ptr_r, g.eid_r, short, Be, e)
+    with pytest.raises(RuntimeError, match="row id|neighbour id|indices"):
+        ops.vector_spmm_backward(*a8, e, short, A)
+    with pytest.raises(RuntimeError, match="row id|only|indices"):
+        ops.vector_spmm_backward(*a8, e, A, short)
+
+
+def test_interleaved_empty_chunks(dev):
+    """Hand-built layouts with empty chunks between the chunks of a row: the sorted-ids check looks
+    past them (unsorted rows must not reach the window drivers) and block detection skips them."""
+    src = torch.tensor([0, 0, 0, 0, 1, 1, 2, 2, 2]); dst = torch.tensor([5, 1, 3, 2, 0, 4, 2, 2, 5])   # row 0 NOT sorted by id
+    n = 6
+    order = torch.argsort(src, stable=True)
+    src, dst = src[order], dst[order]
+    row = torch.tensor([0, 0, 0, 1, 1, 2, 2]); ptr = torch.tensor([0, 2, 2, 4, 6, 6, 6, 9])   # empty chunks inside rows 0, 1, 2
+    eid = torch.arange(9)
+    Q = torch.rand(3, 16); K = torch.rand(n, 16)
+    want = oracle.maskedmm_csr_forward(row, ptr, eid, dst, Q, K)
+    _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 1); _lib.tune("sweep_min_granule", 0); _lib.clear_plan_cache()
+    try:
+        got = ops.maskedmm_csr_forward(row.to(dev), ptr.to(dev), eid.to(dev), dst.to(dev), Q.to(dev), K.to(dev))
+        w = torch.rand(9)
+        o = ops.vector_spmm_forward(row.to(dev), ptr.to(dev), eid.to(dev), dst.to(dev), w.to(dev), K.to(dev))
+    finally:
+        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+    close(got, want)
+    close(o[:3], oracle.vector_spmm_forward(row, ptr, eid, dst, w, K)[:3])
+
+
 def test_torch_ops_namespace_on_gpu(dev):
     g = graphs.uniform_random_graph(64, 2000, seed=3).to(dev)
     A = torch.rand(64, 64, device=dev); B = torch.rand(64, 64, device=dev)
