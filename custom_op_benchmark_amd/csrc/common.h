@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
+
 #include "graphop_hip.h"
 
 namespace graphop {
@@ -141,6 +143,103 @@ __device__ __forceinline__ float group_sum_rt(float v, int g) {  // g wave-unifo
     case 32: return group_sum<32>(v);
     case 64: return group_sum<64>(v);
     default: return v;
+  }
+}
+
+// ---- compile-time loops and lane-group broadcasts ------------------------------------------------
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(<N-1>)
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Value held by lane U of every aligned group of L lanes, without an LDS round trip where the
+// hardware allows: L = 16 is one DPP row (row_newbcast, and the compiler folds it into the consuming
+// add: v_add_u32_dpp), L = 4 a quad_perm, L = 64 a readlane (scalar), L = 8 / 32 two of those and a
+// select.  The strips issue one of these per slot; as ds_bpermute each cost an LDS-pipeline round
+// trip (~100 cycles) in front of the row request it feeds.
+template <int L, int U>
+__device__ __forceinline__ int group_bcast(int v) {
+  static_assert(U >= 0 && U < L, "lane out of range");
+  if constexpr (L == 16) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
+  } else if constexpr (L == 4) {
+    return __builtin_amdgcn_update_dpp(0, v, U * 0x55, 0xF, 0xF, true);
+  } else if constexpr (L == 8) {
+    const int lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, v, 0x150 + U + 8, 0xF, 0xF, true);
+    return (threadIdx.x & 8) ? hi : lo;
+  } else if constexpr (L == 64) {
+    return __builtin_amdgcn_readlane(v, U);
+  } else if constexpr (L == 32) {
+    const int lo = __builtin_amdgcn_readlane(v, U);
+    const int hi = __builtin_amdgcn_readlane(v, U + 32);
+    return (threadIdx.x & 32) ? hi : lo;
+  } else {
+    return __shfl(v, U, L);
+  }
+}
+template <int L, int U>
+__device__ __forceinline__ unsigned group_bcast(unsigned v) { return (unsigned)group_bcast<L, U>((int)v); }
+template <int L, int U>
+__device__ __forceinline__ float group_bcast(float v) {
+  return __builtin_bit_cast(float, group_bcast<L, U>(__builtin_bit_cast(int, v)));
+}
+
+// p[u] = this lane's partial of slot u's dot product.  Returns, in lane u of every group, the sum of
+// p[u] over the group's L lanes (other lanes: unspecified).  For a 16-lane group and 16 slots this is
+// a transpose-reduce: every step halves the number of live values (the lane keeps the slots whose
+// index bit matches its own lane bit and adds its partner's partials of those slots): 45 VALU
+// instructions instead of 16 x (4 DPP adds + a select) = 80.
+template <int L, int SB>
+__device__ __forceinline__ float group_dots_to_owner(float (&p)[SB], int l) {
+  if constexpr (L == 16 && SB == 16) {
+    float t8[8], t4[4], t2[2];
+    const bool b3 = l & 8, b2 = l & 4, b1 = l & 2, b0 = l & 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float keep = b3 ? p[u + 8] : p[u], send = b3 ? p[u] : p[u + 8];
+      t8[u] = keep + dpp_f32<0x128>(send);      // row_ror:8 = lane ^ 8
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float keep = b2 ? t8[u + 4] : t8[u], send = b2 ? t8[u] : t8[u + 4];
+      t4[u] = keep + dpp_f32<0x141>(send);      // row_half_mirror: flips bits 0-2, keeps bit 3
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float keep = b1 ? t4[u + 2] : t4[u], send = b1 ? t4[u] : t4[u + 2];
+      t2[u] = keep + dpp_f32<0x4E>(send);       // quad_perm [2,3,0,1] = lane ^ 2
+    }
+    const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
+    return keep + dpp_f32<0xB1>(send);          // quad_perm [1,0,3,2] = lane ^ 1
+  } else if constexpr (L == 16 && SB == 8) {   // lanes u and u + 8 both end up with slot u's sum
+    float t4[4], t2[2];
+    const bool b2 = l & 4, b1 = l & 2, b0 = l & 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float keep = b2 ? p[u + 4] : p[u], send = b2 ? p[u] : p[u + 4];
+      t4[u] = keep + dpp_f32<0x141>(send);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float keep = b1 ? t4[u + 2] : t4[u], send = b1 ? t4[u] : t4[u + 2];
+      t2[u] = keep + dpp_f32<0x4E>(send);
+    }
+    const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
+    const float r = keep + dpp_f32<0xB1>(send);
+    return r + dpp_f32<0x128>(r);
+  } else {
+    float res = 0.f;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const float s = group_sum<L>(p[u]);
+      if (l == u) res = s;
+    }
+    return res;
   }
 }
 

@@ -126,8 +126,10 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   // Cache) and vrows twice as long -- measured on Reddit-shape: 2.25 ms at W=8 vs 2.46 at W=16.
   int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
                 t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
-  if (opts && opts->window_scale > 0) coarse = opts->window_scale;
-  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024));
+  // the fused kernels state their window size directly (their packed rows are twice as wide)
+  const i64 win_kb = (opts && opts->window_scale > 0) ? (i64)t.window_kb * opts->window_scale : (i64)t.window_kb;
+  if (opts && opts->window_scale > 0) coarse = 1;
+  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, win_kb * 1024));
   if (!force_windows && t.sweep_w > 0) W = t.sweep_w;   // experiments: window count given directly
   if (!force_windows && !windows_ok(W)) {
     coarse = 1;   // Infinity-Cache tier: windows are sized for that cache, not for the flush count
@@ -157,7 +159,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
     i64 target = pi.n_edges / (resident_vrows > 0 ? resident_vrows : 1);
     i64 p2 = 64;
     while (p2 * 2 <= target && p2 < 4096) p2 <<= 1;
-    T = (int)(p2 * coarse);
+    T = (int)(p2 * coarse * ((opts && opts->window_scale > 0) ? opts->window_scale : 1));
   }
   const Sweep* sw = nullptr;
   const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);

@@ -115,22 +115,21 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
     const unsigned my_off = OFF32 ? (unsigned)cur.src * ROWB : (unsigned)cur.src;
     const unsigned my_koff = (unsigned)cur.k * ROWB;
     float4 x0[SB][NV], x1[SB][NV];
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const unsigned o = __shfl(my_off, u, L);
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned o = group_bcast<L, u>(my_off);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if constexpr (OFF32) {
-          const char* rowp = reinterpret_cast<const char*>(XT) + o + (v * L + l) * 16;
-          x0[u][v] = *reinterpret_cast<const float4*>(rowp);
-          x1[u][v] = *reinterpret_cast<const float4*>(rowp + F4 * 16);
+          x0[u][v] = ld4_off(XT, o + (unsigned)((v * L + l) * 16));
+          x1[u][v] = ld4_off(XT, o + (unsigned)((F4 + v * L + l) * 16));
         } else {
           const float4* rowp = reinterpret_cast<const float4*>(XT) + (i64)o * (2 * F4) + v * L + l;
           x0[u][v] = rowp[0];
           x1[u][v] = rowp[F4];
         }
       }
-    }
+    });
     // ids / statistics of the following batches (issued behind the row requests)
     if constexpr (COL) {
       p1 = p2;
@@ -139,10 +138,10 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
     } else {
       stage_a(jb + SB, p1);
     }
-    float my_s = 0.f, my_da = 0.f;
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const unsigned ko = __shfl(my_koff, u, L);
+    float ps[SB], pd[SB];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned ko = group_bcast<L, u>(my_koff);
       float p = 0.f, q = 0.f;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -151,10 +150,10 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
         if (v == 0) { p = dot4(y0, x0[u][0]); q = dot4(y1, x1[u][0]); }
         else { p += dot4(y0, x0[u][v]); q += dot4(y1, x1[u][v]); }
       }
-      p = group_sum<L>(p);
-      q = group_sum<L>(q);
-      if (l == u) { my_s = p; my_da = q; }
-    }
+      ps[u] = p; pd[u] = q;
+    });
+    const float my_s = group_dots_to_owner<L, SB>(ps, l);
+    const float my_da = group_dots_to_owner<L, SB>(pd, l);
     // lane u < SB owns slot u: one exp per slot, then broadcast
     float st_m, st_linv, st_D;
     if constexpr (COL) {
@@ -167,14 +166,14 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
       a_l = expf(my_s - st_m) * st_linv;
       ds_l = a_l * (my_da - st_D);
     }
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const int kt = __shfl(cur.k, u, L);
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int kt = group_bcast<L, u>(cur.k);
       if (kt != k_cur) {   // group-uniform
         spill();
         k_cur = kt;
       }
-      const float dsu = __shfl(ds_l, u, L);
+      const float dsu = group_bcast<L, u>(ds_l);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         acc0[v].x = fmaf(dsu, x0[u][v].x, acc0[v].x);
@@ -183,7 +182,7 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
         acc0[v].w = fmaf(dsu, x0[u][v].w, acc0[v].w);
       }
       if constexpr (COL) {
-        const float au = __shfl(a_l, u, L);
+        const float au = group_bcast<L, u>(a_l);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           acc1[v].x = fmaf(au, x1[u][v].x, acc1[v].x);
@@ -192,7 +191,7 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
           acc1[v].w = fmaf(au, x1[u][v].w, acc1[v].w);
         }
       }
-    }
+    });
   }
   spill();
 }

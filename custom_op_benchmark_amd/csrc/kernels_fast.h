@@ -67,6 +67,11 @@ __device__ __forceinline__ float4 ld_row(const float* base, int src, int f4_in_r
   }
 }
 
+// 16 bytes at base + off, off < 4 GiB: scalar base + 32-bit vector offset (no 64-bit VALU add)
+__device__ __forceinline__ float4 ld4_off(const float* base, unsigned off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (size_t)off);
+}
+
 template <bool NT, typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
@@ -392,17 +397,17 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
     const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
     const unsigned my_off = OFF32 ? (unsigned)nsrc * (unsigned)(F4 * 16) : (unsigned)nsrc;
     float4 b[SB][NV];
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const unsigned o = __shfl(my_off, u, L);
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned o = group_bcast<L, u>(my_off);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if constexpr (OFF32)
-          b[u][v] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(B) + o + (v * L + l) * 16);
+          b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
         else
           b[u][v] = reinterpret_cast<const float4*>(B)[(i64)o * F4 + v * L + l];
       }
-    }
+    });
     if constexpr (H1) {
       if (prev_e >= 0) y[prev_e] = prev_res;
     }
@@ -418,22 +423,22 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       }
     }
     float res = 0.f;
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
+    float part[H1 ? SB : 1];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
       const bool live = u < nb;
       // A row of this slot's vrow straight from LDS every time: no branch, so the batch stays one
-      // basic block and the 16 dot products / DPP reductions interleave
-      const unsigned ko = __shfl(my_koff, u, L);
+      // basic block and the 16 dot products / reductions interleave
+      const unsigned ko = group_bcast<L, u>(my_koff);
 #pragma unroll
       for (int v = 0; v < NV; ++v) a[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
       if constexpr (H1) {
         float p = dot4(a[0], b[u][0]);
 #pragma unroll
         for (int v = 1; v < NV; ++v) p += dot4(a[v], b[u][v]);
-        p = group_sum<L>(p);
-        if (l == u) res = p;
+        part[u] = p;
       } else {
-        const i64 e = __shfl(my_e, u, L);
+        const i64 e = group_bcast<L, u>(my_e);
         if (d4 >= L) {
           const int sph = d4 / L;
           float acc = 0.f;
@@ -455,7 +460,8 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
           }
         }
       }
-    }
+    });
+    if constexpr (H1) res = group_dots_to_owner<L, SB>(part, l);
     if constexpr (H1) {
       prev_res = res;
       prev_e = l < nb ? my_e : -1;
@@ -523,22 +529,22 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
     const float my_w = p1.w;
     float4 x[SB][NV];
     float wt[H1 ? 1 : SB][H1 ? 1 : NV];   // per-head weights are loads and must be issued early
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const unsigned o = __shfl(my_off, u, L);
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned o = group_bcast<L, u>(my_off);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if constexpr (OFF32)
-          x[u][v] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + o + (v * L + l) * 16);
+          x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
         else
           x[u][v] = reinterpret_cast<const float4*>(X)[(i64)o * F4 + v * L + l];
       }
       if constexpr (!H1) {
-        const i64 e = __shfl(my_e, u, L);
+        const i64 e = group_bcast<L, u>(my_e);
 #pragma unroll
         for (int v = 0; v < NV; ++v) wt[u][v] = u < nb ? w[e * h + hv[v]] : 0.f;
       }
-    }
+    });
     // ids of the following batches (issued after the row requests so they stay in flight behind them)
     if constexpr (EID_ID) {
       stage_a(jb + SB, p1);
@@ -547,15 +553,15 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
       stage_b(p1);
       stage_a(jb + 2 * SB, p2);
     }
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const int kt = __shfl(my_k, u, L);
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int kt = group_bcast<L, u>(my_k);
       if (kt != k_cur) {   // group-uniform
         spill();
         k_cur = kt;
       }
       float w1 = 0.f;
-      if constexpr (H1) w1 = __shfl(my_w, u, L);
+      if constexpr (H1) w1 = group_bcast<L, u>(my_w);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const float ww = H1 ? w1 : wt[H1 ? 0 : u][H1 ? 0 : v];
@@ -564,7 +570,7 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
         acc[v].z = fmaf(ww, x[u][v].z, acc[v].z);
         acc[v].w = fmaf(ww, x[u][v].w, acc[v].w);
       }
-    }
+    });
   }
   spill();
 }

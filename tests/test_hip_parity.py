@@ -240,7 +240,7 @@ def test_out_of_range_row_ids_raise(dev):
     a4, a8 = (g.row, g.ptr_r, g.eid_r, g.indices_r), g.csr_args()
     with pytest.raises(RuntimeError, match="row id"):
         ops.maskedmm_csr_forward(*a4, short, A)
-    with pytest.raises(RuntimeError, match="row id|neighbour id"):
+    with pytest.raises(RuntimeError, match="row id|neighbour id|indices"):
         ops.maskedmm_csr_backward(*a8, short, A, e)
     with pytest.raises(RuntimeError, match="row id|neighbour id|indices"):
         ops.maskedmm_csr_backward(*a8, A, short, e)
@@ -393,7 +393,7 @@ def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d, mode):
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
-    """Same inputs through both drivers: SDDMM bit-identical, SpMM within fp32 re-association."""
+    """Same inputs through both drivers: equal within fp32 re-association."""
     _lib.tune("sweep_mode", mode)
     g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
     gen = torch.Generator(device=dev).manual_seed(2)
@@ -405,8 +405,9 @@ def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
         ch = hip_step(g, Q, K, V, dO)
     finally:
         _lib.tune("sweep", 1)
-    assert torch.equal(sw["s"], ch["s"])
-    for k in ("a", "o", "dQ", "dK", "dV"):
+    # (the strips reduce a batch of 16 dots by a transpose-reduce, the chunk driver slot by slot:
+    # same products, different summation tree)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
         torch.testing.assert_close(sw[k], ch[k], rtol=1e-4, atol=1e-5)
 
 

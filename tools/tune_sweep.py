@@ -14,7 +14,8 @@ from custom_op_benchmark_amd import _lib, graphs, functions
 
 DEFAULTS = dict(sweep=1, sweep_mode=1, window_kb=4096, mall_window_kb=32768, max_windows=128,
                 sweep_min_kb=4608, sweep_bpc=4, sweep_k=0, vrow_t=0, sweep_drift=2, sweep_min_granule=4,
-                sweep_prefetch=0, transpose_scalars=0, sweep_w=0, spmm_window_scale=2)
+                sweep_prefetch=0, transpose_scalars=0, sweep_w=0, spmm_window_scale=2,
+                attn_fused=1, attn_window_scale=2, attn_k=0, attn_bpc=0)
 
 
 def main():
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--fused", action="store_true", help="time the fused op (FusedAttention) instead of the 8-function step")
     ap.add_argument("settings", nargs="*", default=[""])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,6 +41,10 @@ def main():
         t.requires_grad_(True)
     order = ["sddmm_fwd", "softmax_fwd", "spmm_fwd", "spmm_bwd_dedata", "spmm_bwd_dx", "softmax_bwd",
              "sddmm_bwd_dA", "sddmm_bwd_dB"]
+    step = functions.attention_step
+    if args.fused:
+        order = ["sddmm_fwd", "softmax_fwd", "spmm_fwd", "attn_pack", "attn_bwd_row", "attn_bwd_col"]
+        step = functions.fused_attention_step
     print("# N=%d E=%d h=%d d=%d ; columns: step-wall (sum of pass times) " % (N, E, args.heads, args.d) + " ".join(order), flush=True)
     for setting in args.settings:
         knobs = dict(DEFAULTS)
@@ -49,18 +55,18 @@ def main():
             _lib.tune(k, v)
         _lib.clear_plan_cache()
         for _ in range(2):
-            functions.attention_step(g, Q, K, V, dO)
+            step(g, Q, K, V, dO)
         torch.cuda.synchronize()
         _lib.profile_enable(True)
         for _ in range(args.steps):
-            functions.attention_step(g, Q, K, V, dO)
+            step(g, Q, K, V, dO)
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         t0.record()
         for _ in range(args.steps):
-            functions.attention_step(g, Q, K, V, dO)
+            step(g, Q, K, V, dO)
         t1.record(); torch.cuda.synchronize()
         wall = t0.elapsed_time(t1) / args.steps
         ms = [prof[n]["mean_ms"] if n in prof else float("nan") for n in order]
