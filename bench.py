@@ -8,18 +8,25 @@ dominant kernel and the CPU PyTorch scatter/gather baseline (BASELINE.json metri
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = s = MaskedMMCSR(Q,K); a = SparseSoftmax(s); o = VectorSPMM(a,V); o.backward(dO)
-through the product's autograd classes (the reference's usage, wrapper.py:201-206,231-239,291-299).
+through the product's autograd classes (the reference's usage, wrapper.py:201-206,231-239,291-299):
+the reference's eight-function operator surface.  `value` is ALWAYS that step.  The same step
+through the extra fused op (functions.FusedAttention) is measured next to it and reported under
+"fused" -- a secondary figure, never `value`.
 Inputs are synthetic (no datasets in the image): Chung-Lu power-law graph, U[0,1) features like
-the reference harness (wrapper.py:151-153); they are resident in HBM before the timed region.
-Graph preprocessing (CSR build, partition_csr, per-graph plans) is setup and reported separately.
+the reference harness (wrapper.py:151-153; --values normal gives N(0,1)/sqrt(d)); they are resident
+in HBM before the timed region.  Graph preprocessing (CSR build, partition_csr, per-graph plans) is
+setup and reported separately.
 
-At N > 1 the graph is node-range partitioned (custom_op_benchmark_amd.dist): every rank owns the
-rows of one Reddit-shaped shard of an N-times larger graph (weak scaling) and exchanges halo
-K/V rows and dK/dV partial rows by RCCL all-to-all each step.
+Workloads (--graph): N = 1 defaults to BASELINE.json config 2 (reddit).  N > 1 (and --emulate-world)
+default to config 4: every rank owns one 1/8 shard of a papers100M-shaped graph (13.9 M nodes,
+202 M edges, d = 128) -- weak scaling, node-range partition (custom_op_benchmark_amd.dist), halo K/V
+rows and dK/dV partial rows by RCCL all-to-all each step.  `--graph rmat25` is config 5 (d = 256).
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,8 +36,12 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+# random whole-row gathers of a table far beyond the Infinity Cache, each row fetched once
+# (MI355X_MICROARCH.md, "Indexed rows": 5.5-5.8 TB/s for 1-2 KB rows)
+HBM_RANDOM_ROW_GBS = 5700.0
 PASS_TAGS = ["sddmm_fwd", "softmax_fwd", "spmm_fwd", "spmm_bwd_dedata", "spmm_bwd_dx", "softmax_bwd",
              "sddmm_bwd_dA", "sddmm_bwd_dB"]
+GATHER_TAGS = [t for t in PASS_TAGS if not t.startswith("softmax")]
 
 
 def pass_bytes(E, N_rows, N_cols, h, d, C, Cc):
@@ -50,39 +61,16 @@ def pass_bytes(E, N_rows, N_cols, h, d, C, Cc):
     }
 
 
-KERNEL_OF = {  # pass tag -> device kernel family that executes it
-    "sddmm_fwd": "k_sddmm_f32", "spmm_bwd_dedata": "k_sddmm_f32",
-    "spmm_fwd": "k_spmm_f32", "spmm_bwd_dx": "k_spmm_f32", "sddmm_bwd_dA": "k_spmm_f32",
-    "sddmm_bwd_dB": "k_spmm_f32", "softmax_fwd": "k_softmax_fwd_seg", "softmax_bwd": "k_softmax_bwd_seg",
-}
-
-
-def cpu_baseline(g, Q, K, V, dO, sample_edges, log):
-    """The reference's CPU-runnable path (stock PyTorch gather/scatter, oracle/torch_path.py) timed
-    on this box's host cores on a bounded row-block sample of the same graph."""
-    from oracle import torch_path
-    E = g.n_edges
-    ip = g.indptr_r
-    target = min(E, sample_edges)
-    R = int(torch.searchsorted(ip, torch.tensor([target], device=ip.device))[0].item())
-    R = max(1, min(R, g.n_src))
-    ipc = ip[: R + 1].cpu()
-    e1 = int(ipc[-1])
-    dst = g.indices_r[:e1].cpu()
-    src = torch.repeat_interleave(torch.arange(R), ipc[1:] - ipc[:-1])
-    Qc, Kc, Vc, dOc = Q[:R].cpu(), K.cpu(), V.cpu(), dO[:R].cpu()
-    times = []
-    for it in range(4):
-        t0 = time.perf_counter()
-        torch_path.attention_step_blocked(src, dst, ipc, Qc, Kc, Vc, dOc, R, rows_per_block=2048)
-        times.append(time.perf_counter() - t0)
-        log("cpu_baseline rep %d: %.2f s for %d edges" % (it, times[-1], e1))
-    times = sorted(times[1:])
-    med = times[len(times) // 2]
-    return {"value": e1 / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "rows [0,%d) of the same graph = %d edges (%.2f%% of E), K/V/dK/dV full size; "
-                      "stock-PyTorch gather/scatter step (oracle/torch_path.py), median of 3 after 1 warm-up, "
-                      "%.2f s/step; host %s, os.cpu_count()=%d" % (R, e1, 100.0 * e1 / E, med, _cpu_model(), os.cpu_count())}
+def kernels_sha():
+    """Hash of the kernel sources: a PMC traffic record is only quoted for the kernels it was
+    collected on (profiles/pmc_traffic.json carries the hash of its build)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "custom_op_benchmark_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _cpu_model():
@@ -95,17 +83,61 @@ def _cpu_model():
     return "unknown"
 
 
+def cpu_baseline(g, Q, K, V, dO, sample_edges, log, incidence=False):
+    """The reference's CPU-runnable path (stock PyTorch gather/scatter, oracle/torch_path.py) timed
+    on this box's host cores on a bounded row-block sample of the same graph.  incidence=True adds
+    the harness-verbatim copy-to-edge form through incidence matrices (wrapper.py:155-157, 57-75),
+    which only fits small graphs (Cora-shape)."""
+    from oracle import torch_path
+    E = g.n_edges
+    ip = g.indptr_r
+    target = min(E, sample_edges)
+    R = int(torch.searchsorted(ip, torch.tensor([target], device=ip.device))[0].item())
+    R = max(1, min(R, g.n_src))
+    ipc = ip[: R + 1].cpu()
+    e1 = int(ipc[-1])
+    dst = g.indices_r[:e1].cpu()
+    src = torch.repeat_interleave(torch.arange(R), ipc[1:] - ipc[:-1])
+    Qc, Kc, Vc, dOc = Q[:R].cpu(), K.cpu(), V.cpu(), dO[:R].cpu()
+
+    def timed(fn, reps):
+        ts = []
+        for it in range(reps + 1):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            log("cpu_baseline rep %d: %.3f s for %d edges" % (it, ts[-1], e1))
+        return statistics.median(ts[1:])
+
+    med = timed(lambda: torch_path.attention_step_blocked(src, dst, ipc, Qc, Kc, Vc, dOc, R, rows_per_block=2048), 3)
+    out = {"value": e1 / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "rows [0,%d) of the same graph = %d edges (%.2f%% of E), K/V/dK/dV full size; "
+                     "stock-PyTorch gather/scatter step (oracle/torch_path.py), median of 3 after 1 warm-up, "
+                     "%.3f s/step; host %s, os.cpu_count()=%d" % (R, e1, 100.0 * e1 / E, med, _cpu_model(), os.cpu_count())}
+    if incidence:
+        med_i = timed(lambda: torch_path.attention_step_incidence(src, dst, Qc, Kc, Vc, dOc, R), 3)
+        out["incidence_form"] = {"value": e1 / med_i, "unit": "edges/s", "s_per_step": round(med_i, 4),
+                                 "what": "harness-verbatim copy-to-edge SDDMM through sparse incidence matrices "
+                                         "(wrapper.py:155-157) + th.sparse.mm SpMM (wrapper.py:274), same sample"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--graph", default="reddit", help="reddit | products | cora | harness | custom")
+    ap.add_argument("--graph", default="auto",
+                    help="auto | reddit | products | cora | harness | papers100m | rmat25 | custom")
     ap.add_argument("--nodes", type=int, default=0)
     ap.add_argument("--edges", type=int, default=0)
-    ap.add_argument("--d", type=int, default=64, help="per-head feature dim")
+    ap.add_argument("--d", type=int, default=0, help="per-head feature dim (0 = the workload's default)")
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--alpha", type=float, default=0.5, help="Chung-Lu power-law exponent (0 = uniform)")
+    ap.add_argument("--values", default="uniform", help="uniform: U[0,1) like the harness | normal: N(0,1)/sqrt(d)")
+    ap.add_argument("--cut", type=float, default=-1.0,
+                    help="sharded graphs: fraction of a rank's edges whose destination is drawn from the GLOBAL "
+                         "node distribution (the rest stay in the rank's range); default 0.1 for papers100m, 1 otherwise")
     ap.add_argument("--chunk-size", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample-edges", type=int, default=3_000_000)
@@ -113,7 +145,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal: build rank 0's shard of a WORLD-way partition and time its "
-                         "local compute (collectives replaced by local copies); not a headline number")
+                         "local compute (exchanges replaced by local copies of the right sizes); timing only")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the step once into a HIP graph and time its replays (single GPU; for the "
                          "launch-bound small shapes -- the headline line is measured with eager API calls)")
@@ -149,44 +181,64 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.graph == "custom" or args.nodes or args.edges:
+    sharded = world > 1 or args.emulate_world > 1
+    n_parts = world if world > 1 else max(1, args.emulate_world)
+    name = args.graph
+    if name == "auto":
+        name = "papers100m" if sharded else "reddit"
+    if name == "custom" or args.nodes or args.edges:
         N, E = args.nodes, args.edges
         name = "custom"
     else:
-        N, E = graphs.SHAPES[args.graph]
-        name = args.graph
-    h, d = args.heads, args.d
+        N, E = graphs.SHAPES[name]
+        if name in graphs.SHARDS_OF:          # one shard of the 8-way partition per GPU
+            N, E = N // graphs.SHARDS_OF[name], E // graphs.SHARDS_OF[name]
+    h = args.heads
+    d = args.d or graphs.DEFAULT_D.get(name, 64)
+    cut = args.cut if args.cut >= 0 else (0.1 if name == "papers100m" else 1.0)
 
     # ---- setup (not timed as part of a step; reported) -------------------------------------------
     t_setup = time.perf_counter()
-    if world == 1 and args.emulate_world > 1:
+    runner = None
+    gdesc = "Chung-Lu(alpha=%.2f)" % args.alpha
+    if sharded:
         from custom_op_benchmark_amd import dist as gdist
-        runner = gdist.ShardedAttention.synthetic(N, E, args.emulate_world, 0, dev, alpha=args.alpha,
-                                                  seed=args.seed, chunk_size=args.chunk_size, emulate=True)
+        kw = dict(chunk_size=args.chunk_size, timing_only=(world == 1))
+        if name == "rmat25":
+            runner = gdist.ShardedAttention.synthetic_rmat(25 - 3 + (n_parts - 1).bit_length(), E, n_parts,
+                                                           rank, dev, seed=args.seed, **kw)
+            gdesc = "R-MAT(0.57,0.19,0.19,0.05) scale %d, equal node ranges" % (25 - 3 + (n_parts - 1).bit_length())
+        else:
+            runner = gdist.ShardedAttention.synthetic(N, E, n_parts, rank, dev, alpha=args.alpha, seed=args.seed,
+                                                      cut=cut, **kw)
+            gdesc += ", %.0f%% of a rank's edges drawn from the global node distribution" % (100 * cut)
         g = runner.graph
-        n_rows, n_cols = g.n_src, g.n_dst
-    elif world == 1 and name == "harness":
+    elif name == "harness":
         # the reference author's own fixture: 512 disjoint complete digraphs of 30 nodes (wrapper.py:79-112)
         g = graphs.block_diagonal_graph(512, 30, chunk_size=args.chunk_size, device=dev)
-        runner = None
-        n_rows, n_cols = g.n_src, g.n_dst
-    elif world == 1:
-        g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev)
-        runner = None
-        n_rows, n_cols = g.n_src, g.n_dst
+        gdesc = "block-diagonal: 512 disjoint complete digraphs of 30 nodes (wrapper.py:79-112)"
+    elif name == "rmat25":
+        src, dst = graphs.rmat_edges(22, E, seed=args.seed, device=dev)
+        g = graphs.graph_from_coo(src, dst, 1 << 22, 1 << 22, args.chunk_size)
+        N = 1 << 22
+        gdesc = "R-MAT(0.57,0.19,0.19,0.05) scale 22 (one eighth of scale 25)"
+        del src, dst
     else:
-        from custom_op_benchmark_amd import dist as gdist
-        runner = gdist.ShardedAttention.synthetic(N, E, world, rank, dev, alpha=args.alpha, seed=args.seed,
-                                                  chunk_size=args.chunk_size)
-        g = runner.graph
-        n_rows, n_cols = g.n_src, g.n_dst
+        g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev)
+    n_rows, n_cols = g.n_src, g.n_dst
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1 + rank)
     shp = (lambda n: (n, d) if h == 1 else (n, h, d))
-    n_own = N if runner is None else runner.n_own
-    Q = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
-    K = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
-    V = torch.rand(shp(n_own), device=dev, generator=gen).requires_grad_(True)
-    dO = torch.rand(shp(n_own), device=dev, generator=gen)
+    n_own = n_rows if runner is None else runner.n_own
+
+    def values(n):
+        if args.values == "normal":
+            return torch.randn(shp(n), device=dev, generator=gen) / (d ** 0.5)
+        return torch.rand(shp(n), device=dev, generator=gen)
+
+    Q = values(n_own).requires_grad_(True)
+    K = values(n_own).requires_grad_(True)
+    V = values(n_own).requires_grad_(True)
+    dO = values(n_own)
     torch.cuda.synchronize()
     t_graph = time.perf_counter() - t_setup
 
@@ -228,12 +280,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the timed region: exactly K steps between two barrier + synchronize pairs (wall clock, max over
+    # ranks); per-step hipEvents on the launch stream give the median / min the roofline is read at
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         timed_step()
+        evs[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if world > 1:
         cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -255,12 +313,16 @@ def main():
             functions.fused_attention_step(g, Q, K, V, dO)
         for _ in range(max(2, args.warmup)):
             fstep()
+        fev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        fev[0].record()
+        for i in range(args.steps):
             fstep()
+            fev[i + 1].record()
         torch.cuda.synchronize()
         f_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        f_step = [fev[i].elapsed_time(fev[i + 1]) for i in range(args.steps)]
         _lib.profile_enable(True)
         for _ in range(max(1, args.profile_steps)):
             fstep()
@@ -268,12 +330,16 @@ def main():
         fprof = _lib.profile_read()
         _lib.profile_enable(False)
         fused = {"ms_per_step": round(f_ms, 4), "value": g.n_edges / (f_ms * 1e-3), "unit": "edges/s",
-                 "op": "FusedAttention (attention_forward / attention_backward)",
-                 "passes_ms": {k: round(v["mean_ms"], 4) for k, v in fprof.items()}}
+                 "step_ms_median": round(statistics.median(f_step), 4), "step_ms_min": round(min(f_step), 4),
+                 "op": "FusedAttention = attention_forward + attention_backward (extra op; same o, dQ, dK, dV as "
+                       "the 8-function step, s / a / da / ds never materialised in the backward)",
+                 "passes_ms": {k: round(v["mean_ms"] * v["calls"] / max(1, args.profile_steps), 4) for k, v in fprof.items()},
+                 "kernels": {k: v["kernel"] for k, v in fprof.items()}}
 
     # ---- per-kernel durations, live, hipEvents on the launch stream --------------------------------
+    nprof = max(1, args.profile_steps)
     _lib.profile_enable(True)
-    for _ in range(max(1, args.profile_steps)):
+    for _ in range(nprof):
         step()
     torch.cuda.synchronize()
     prof = _lib.profile_read()
@@ -287,34 +353,58 @@ def main():
         if tag not in prof:
             continue
         ms = prof[tag]["mean_ms"]
-        passes[tag] = {"ms": round(ms, 4), "alg_GB": round(pb[tag] / 1e9, 4),
+        kname = prof[tag]["kernel"] or "?"
+        passes[tag] = {"ms": round(ms, 4), "kernel": kname, "alg_GB": round(pb[tag] / 1e9, 4),
                        "alg_GBps": round(pb[tag] / 1e6 / ms, 1), "frac": round(pb[tag] / 1e6 / ms / HBM_PEAK_GBS, 4)}
-        k = kern.setdefault(KERNEL_OF[tag], {"ms": 0.0, "bytes": 0.0, "launches": 0})
-        k["ms"] += ms; k["bytes"] += pb[tag]; k["launches"] += 1
-    dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else ("none", {"ms": 1.0, "bytes": 0.0, "launches": 1})
+        fam = "k_spmm_*" if kname.startswith("k_spmm") else ("k_sddmm_*" if kname.startswith("k_sddmm") else kname)
+        k = kern.setdefault(fam, {"ms": 0.0, "bytes": 0.0, "launches": 0, "names": set()})
+        k["ms"] += ms; k["bytes"] += pb[tag]; k["launches"] += 1; k["names"].add(kname)
+    other = {t: {"ms_per_step": round(v["total_ms"] / nprof, 4), "launches_per_step": v["calls"] // nprof,
+                 "kernel": v["kernel"]} for t, v in prof.items() if t not in PASS_TAGS}
+    dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else ("none", {"ms": 1.0, "bytes": 0.0, "launches": 1, "names": set()})
+    dom_kernel = "/".join(sorted(dom["names"])) or dom_name
     achieved = dom["bytes"] / 1e6 / dom["ms"]          # GB/s = algorithmic bytes per launch / mean launch time
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    traffic_note = None
+    sha = kernels_sha()
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == "%s_h%d_d%d" % (name, h, d) and dom_name in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
-                traffic_note = tj.get("note")
+            if tj.get("workload") == "%s_h%d_d%d" % (name, h, d) and dom_kernel in tj.get("kernels", {}):
+                if tj.get("kernels_sha") == sha:
+                    traffic = tj["kernels"][dom_kernel]["hbm_bytes_per_launch"]
+                    traffic_src = ("NOT measured in this run: rocprofv3 --pmc passes of this command on the same kernel "
+                                   "sources (kernels_sha %s), profiles/pmc_traffic.json; %s" % (sha, tj.get("note", "")))
+                else:
+                    traffic_src = ("profiles/pmc_traffic.json was collected on other kernel sources (sha %s, now %s): "
+                                   "not quoted" % (tj.get("kernels_sha"), sha))
         except (ValueError, KeyError):
             pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom_name,
-                "launches_per_step": dom["launches"],
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": dom_kernel, "launches_per_step": dom["launches"],
                 "alg_bytes_per_launch": int(dom["bytes"] / max(1, dom["launches"])),
                 "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 4),
                 "step": {"alg_bytes": int(alg_step), "alg_GBps": round(alg_step / 1e6 / ms_per_step, 1),
                          "frac": round(alg_step / 1e6 / ms_per_step / HBM_PEAK_GBS, 4),
-                         "kernel_ms_sum": round(sum(p["ms"] for p in passes.values()), 3)},
-                "passes": passes}
-    if traffic_note:
-        roofline["traffic_note"] = traffic_note
+                         "frac_at_median_step": round(alg_step / 1e6 / statistics.median(step_ms) / HBM_PEAK_GBS, 4),
+                         "kernel_ms_sum": round(sum(p["ms"] for p in passes.values()) +
+                                                sum(o["ms_per_step"] for o in other.values()), 3)},
+                "passes": passes, "other_launches": other}
+    # tables far beyond the Infinity Cache with rows too short for column windows (products-shape): every
+    # gathered edge is an HBM random-row read; what is physically reachable is that rate, not 8 TB/s of
+    # algorithmic bytes -- a labelled secondary figure
+    table_bytes = max(n_rows, n_cols) * h * d * 4
+    if table_bytes > (512 << 20) and passes:
+        gbytes = 6.0 * g.n_edges * h * d * 4
+        gms = sum(passes[t]["ms"] for t in GATHER_TAGS if t in passes)
+        roofline["gather_roofline"] = {
+            "what": "secondary: 6 gather passes x E x F x 4 B of neighbour rows at the measured HBM random-row rate "
+                    "(MI355X_MICROARCH.md, Indexed rows: 5.5-5.8 TB/s); the tables (%.1f GB each) are beyond the Infinity Cache"
+                    % (table_bytes / 1e9),
+            "gather_bytes": int(gbytes), "peak_GBps": HBM_RANDOM_ROW_GBS, "achieved_GBps": round(gbytes / 1e6 / gms, 1),
+            "frac": round(gbytes / 1e6 / gms / HBM_RANDOM_ROW_GBS, 4),
+            "floor_ms_per_step": round(gbytes / 1e6 / HBM_RANDOM_ROW_GBS, 2)}
     # block-dense workloads (harness fixture): the gather passes run as 32x32 fp32-MFMA tiles; report
     # tile flops against the dense fp32 MFMA peak next to the HBM figure (still the binding roofline)
     try:
@@ -331,26 +421,40 @@ def main():
     except Exception as exc:      # reporting only
         log("mfma report skipped: %r" % (exc,))
 
+    cfg = {"workload": "%s-shape %s graph, N=%d E=%d per GPU, h=%d d=%d, %s values, chunk_size=%d, int64 CSR both "
+                       "orientations" % (name, gdesc, n_own, g.n_edges, h, d,
+                                         "U[0,1)" if args.values != "normal" else "N(0,1)/sqrt(d)", args.chunk_size),
+           "graph": name, "nodes": n_rows, "edges": total_edges, "heads": h, "d": d,
+           "chunk_size": args.chunk_size, "row_chunks": g.n_row_chunks, "col_chunks": g.n_col_chunks,
+           "parallelism": ("single GPU" if not sharded else "node-range shards x%d, RCCL all-to-all halo" % n_parts)
+                          + (" [TIMING-ONLY rehearsal of shard 0 of %d on one GPU, exchanges = local copies]" % args.emulate_world
+                             if args.emulate_world > 1 and world == 1 else "")}
+    if runner is not None:
+        cfg["halo"] = runner.halo_stats(h * d * 4)
+        # per-exchange wall times, measured in a separate pass (their syncs defeat the overlap)
+        runner.timers = {}
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        cfg["halo"]["exchange_ms"] = {k: round(1e3 * statistics.median(v), 3) for k, v in runner.timers.items()}
+        runner.timers = None
     out = {
         "metric": "edges/sec fwd+bwd (SDDMM+softmax+SpMM) on Reddit d=64; HBM GB/s vs roofline",
         "value": value, "unit": "edges/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s-shape Chung-Lu(alpha=%.2f) graph, N=%d E=%d per GPU, h=%d d=%d, chunk_size=%d, "
-                               "int64 CSR both orientations" % (name, args.alpha, n_rows if runner is None else runner.n_own,
-                                                                 g.n_edges, h, d, args.chunk_size),
-                   "graph": name, "nodes": n_rows, "edges": total_edges, "heads": h, "d": d,
-                   "chunk_size": args.chunk_size, "row_chunks": g.n_row_chunks, "col_chunks": g.n_col_chunks,
-                   "parallelism": ("single GPU" if world == 1 else "node-range shards x%d, RCCL all-to-all halo" % world)
-                                  + (" [EMULATED shard 0 of %d, no collectives]" % args.emulate_world if args.emulate_world > 1 else "")},
+        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4),
+                    "max": round(max(step_ms), 4), "method": "hipEvents around every timed step on the launch stream"},
+        "config": cfg,
         "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3)},
         "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }
     if fused is not None:
         out["fused"] = fused
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(g, Q.detach(), K.detach(), V.detach(), dO, args.cpu_sample_edges, log)
+    if rank == 0 and world == 1 and runner is None and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, Q.detach(), K.detach(), V.detach(), dO, args.cpu_sample_edges, log,
+                                           incidence=(g.n_edges <= 200_000))
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)

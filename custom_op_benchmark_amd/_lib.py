@@ -31,7 +31,7 @@ class PlanInfo(ctypes.Structure):
 
 
 class ProfileRec(ctypes.Structure):
-    _fields_ = [("name", ctypes.c_char * 48), ("calls", _c64), ("total_ms", ctypes.c_double),
+    _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48), ("calls", _c64), ("total_ms", ctypes.c_double),
                 ("min_ms", ctypes.c_double), ("max_ms", ctypes.c_double)]
 
 
@@ -53,6 +53,8 @@ _SIGNATURES = {
     "graphop_vector_spmm_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_node_mul_edge_forward": [ctypes.c_int] + [_P] * 6 + [_c64] * 5 + [_P, _P],
     "graphop_node_mul_edge_backward": [ctypes.c_int] + [_P] * 8 + [_c64] * 5 + [_P, _P],
+    "graphop_gather_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
+    "graphop_scatter_add_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_attention_workspace_bytes": [ctypes.c_int, ctypes.c_int] + [_c64] * 5 + [_P, _P, _P,
                                                                                        ctypes.POINTER(_c64)],
     "graphop_attention_forward": [ctypes.c_int] + [_P] * 9 + [_c64] * 6 + [_P, _c64, _P, _P],
@@ -187,7 +189,7 @@ def profile_read():
         check(1)
     out = {}
     for r in buf[:min(n, 64)]:
-        out[r.name.decode()] = dict(calls=int(r.calls), total_ms=r.total_ms, mean_ms=r.total_ms / max(1, r.calls),
+        out[r.name.decode()] = dict(kernel=r.kernel.decode(), calls=int(r.calls), total_ms=r.total_ms, mean_ms=r.total_ms / max(1, r.calls),
                                     min_ms=r.min_ms, max_ms=r.max_ms)
     return out
 
@@ -211,3 +213,24 @@ def partition_csr_device(indptr, chunk_size):
         check(lib().graphop_partition_csr_fill(ptr(ip), _vp(first.data_ptr()), n, chunk_size, c,
                                                ptr(row), _vp(out.data_ptr()), stream_of(ip)))
     return row, out
+
+
+# ---- halo pack / unpack (dist.py) ------------------------------------------------------------------
+def gather_rows(src, idx, out=None):
+    """out[i] = src[idx[i]] (HIP pack kernel; `out` = persistent send buffer)."""
+    if out is None:
+        out = src.new_empty((idx.numel(),) + tuple(src.shape[1:]))
+    row = src[0].numel() if src.size(0) else 0
+    with torch.cuda.device(src.device):
+        check(lib().graphop_gather_rows(dtype_code(src), ptr(src), ptr(idx), ptr(out), idx.numel(),
+                                        src.size(0), row, stream_of(src)))
+    return out
+
+
+def scatter_add_rows(dst, idx, src):
+    """dst[idx[i]] += src[i] in place (idx may repeat)."""
+    row = dst[0].numel() if dst.size(0) else 0
+    with torch.cuda.device(dst.device):
+        check(lib().graphop_scatter_add_rows(dtype_code(dst), ptr(src), ptr(idx), ptr(dst), idx.numel(),
+                                             dst.size(0), row, stream_of(dst)))
+    return dst

@@ -85,7 +85,7 @@ inline i64 soft_rows_of(const graphop_plan* plan_r, i64 n_q) {
 template <bool COL>
 int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gathered, const float* own,
                      const float* xt, const float4* st4, float* out0, float* out1, hipStream_t st) {
-  ProfScope prof(tag, st);
+  ProfScope prof(tag, st, "k_attn_bwd_wown_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
   GO_DISPATCH_LNV(F, {
     const bool off32 = n_gathered * 2 * 16LL * L * NV < (1LL << 32);
@@ -198,7 +198,7 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
     GO_HIP(zero_async(dK, sizeof(float) * (size_t)(n_k * F), st));
     GO_HIP(zero_async(dV, sizeof(float) * (size_t)(n_k * F), st));
     {
-      ProfScope prof("attn_pack", st);
+      ProfScope prof("attn_pack", st, "k_attn_pack");
       GO_DISPATCH_LNV((int)F, {
         constexpr int RPB = kFastBlock / L;
         hipLaunchKernelGGL((k_attn_pack<L, NV, false>), dim3((unsigned)ceil_div(n_k, RPB)), dim3(kFastBlock),

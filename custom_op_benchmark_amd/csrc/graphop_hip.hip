@@ -28,12 +28,12 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 // ---- optional per-kernel timing (hipEvents on the launch stream; off by default) -----------------
-struct ProfRec { const char* name; hipEvent_t t0, t1; };
+struct ProfRec { const char* name; const char* kernel; hipEvent_t t0, t1; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
-ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
+ProfScope::ProfScope(const char* n, hipStream_t s, const char* k) : st(s), name(n), kernel(k) {
   if (!g_prof_on) return;
   if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) { t0 = nullptr; return; }
   (void)hipEventRecord(t0, st);
@@ -42,7 +42,7 @@ ProfScope::~ProfScope() {
   if (!t0) return;
   (void)hipEventRecord(t1, st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back({name, t0, t1});
+  g_prof.push_back({name, kernel, t0, t1});
 }
 
 int partition_count(const i64*, i64, i64, i64*, hipStream_t);
@@ -63,6 +63,7 @@ const Tuning& tuning() { return tuning_mut(); }
 // Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
 hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
+  ProfScope prof("zero_fill", st, "k_zero16");
   unsigned char* p = (unsigned char*)ptr;
   const size_t head = (16 - ((uintptr_t)p & 15)) & 15;
   if (head >= bytes || bytes < 64) {
@@ -236,7 +237,7 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   SweepLaunch sl;
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
   if (use != 1) return use;
-  ProfScope prof(tag, st);
+  ProfScope prof(tag, st, sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
   const bool id = plan->info.eid_identity != 0;
   const dim3 grid(sl.blocks), block(kFastBlock);
   const float* a = (const float*)A;
@@ -303,7 +304,7 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
     if (tr < 0) return tr;
     if (tr == 1) { ww = w_slot; id = true; }
   }
-  ProfScope prof(tag, st);
+  ProfScope prof(tag, st, sl.window_owner ? "k_spmm_wown_f32" : "k_spmm_sweep_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
   const float* x = (const float*)X;
   float* o = (float*)out;
@@ -348,7 +349,7 @@ inline int try_sddmm_block(const char* tag, int dtype, const graphop_plan* plan,
                            const void* A, const void* B, void* y, i64 h, i64 d, hipStream_t st) {
   if (!block_ok(plan, dtype, h, d, n_table_rows) || d % 8 != 0 || !aligned16(A) || !aligned16(B)) return 0;
   const int nw = d % 32 == 0 ? 4 : (d % 16 == 0 ? 2 : 1);
-  ProfScope prof(tag, st);
+  ProfScope prof(tag, st, "k_sddmm_block_f32");
   const dim3 grid((unsigned)(plan->info.n_dense_blocks * h)), block(kWave * nw);
   const BlockView bv = block_view(plan);
   if (plan->info.eid_identity)
@@ -381,7 +382,7 @@ inline int try_spmm_block(const char* tag, int dtype, const graphop_plan* plan, 
   const int vw = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);
   const i64 groups = d / (32 * vw);
   const int nw = (int)(groups < 4 ? groups : 4);
-  ProfScope prof(tag, st);
+  ProfScope prof(tag, st, "k_spmm_block_f32");
   const dim3 grid((unsigned)(plan->info.n_dense_blocks * h)), block(kWave * nw);
   const BlockView bv = block_view(plan);
   const bool id = plan->info.eid_identity != 0;
@@ -414,7 +415,7 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
-    ProfScope prof(tag, st);
+    ProfScope prof(tag, st, "k_sddmm_f32");
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
@@ -428,7 +429,7 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
                            C, (int)h, d4, cpg);
     });
   } else {
-    ProfScope prof(tag, st);
+    ProfScope prof(tag, st, "k_sddmm_generic");
     const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
     if (dtype == GRAPHOP_F32)
       hipLaunchKernelGGL((k_sddmm_generic<float, EDGE_B>), dim3(nb), dim3(kGenericBlock), 0, st,
@@ -462,7 +463,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
-    ProfScope prof(tag, st);
+    ProfScope prof(tag, st, "k_spmm_f32");
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
@@ -476,7 +477,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
                            (int)h, d4, cpg);
     });
   } else {
-    ProfScope prof(tag, st);
+    ProfScope prof(tag, st, "k_spmm_generic");
     const unsigned nb = blocks_for(C, kGenericWavesPerBlock);
     if (dtype == GRAPHOP_F32)
       hipLaunchKernelGGL((k_spmm_generic<float, EDGE_X>), dim3(nb), dim3(kGenericBlock), 0, st,
@@ -524,7 +525,7 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
                        const T* in1, T* out, i64 h, hipStream_t st, T* stats = nullptr) {
   const i64 S = p->info.n_segments;
   if (S == 0) return GRAPHOP_OK;
-  ProfScope prof(BWD ? "softmax_bwd" : "softmax_fwd", st);
+  ProfScope prof(BWD ? "softmax_bwd" : "softmax_fwd", st, BWD ? "k_softmax_bwd_seg" : "k_softmax_fwd_seg");
   const bool id = p->info.eid_identity != 0;
   if (pow2(h) && h <= 64) {
     const int G = seg_group_width(p->info.n_edges * h / S, h);
@@ -705,6 +706,7 @@ int graphop_profile_read(graphop_profile_rec_t* out, int cap) {
       graphop_profile_rec_t rec;
       memset(&rec, 0, sizeof(rec));
       strncpy(rec.name, r.name, sizeof(rec.name) - 1);
+      strncpy(rec.kernel, r.kernel ? r.kernel : "", sizeof(rec.kernel) - 1);
       rec.min_ms = ms;
       it = agg.emplace(r.name, rec).first;
       order.push_back(r.name);
@@ -996,7 +998,7 @@ int graphop_node_mul_edge_forward(int dtype, const int64_t* row, const int64_t* 
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B);
   if (nme_fast_ok(dtype, h, d, n_edges)) {
-    ProfScope prof("node_mul_edge_fwd", st);
+    ProfScope prof("node_mul_edge_fwd", st, "k_nme_fwd_f32");
     const int cpg = tuning().spmm_cpg;
     GO_DISPATCH_NME(d, h, {
       const unsigned nb = blocks_for(ceil_div(n_chunks, cpg), kFastBlock / LD);
@@ -1032,7 +1034,7 @@ int graphop_node_mul_edge_backward(int dtype, const int64_t* row, const int64_t*
   if (n_chunks == 0 || h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, A); GO_PTR(fn, B); GO_PTR(fn, dy);
   if (nme_fast_ok(dtype, h, d, n_edges)) {   // both gradients in one streaming pass over B and dy
-    ProfScope prof("node_mul_edge_bwd", st);
+    ProfScope prof("node_mul_edge_bwd", st, "k_nme_bwd_f32");
     const int cpg = tuning().spmm_cpg;
     GO_DISPATCH_NME(d, h, {
       const unsigned nb = blocks_for(ceil_div(n_chunks, cpg), kFastBlock / LD);

@@ -10,7 +10,8 @@ struct ProfScope {
   hipEvent_t t0 = nullptr, t1 = nullptr;
   hipStream_t st;
   const char* name;
-  ProfScope(const char* n, hipStream_t s);
+  const char* kernel;   // device kernel family (string literal), may be set after construction
+  ProfScope(const char* n, hipStream_t s, const char* k = "");
   ~ProfScope();
 };
 

@@ -53,16 +53,95 @@ class _Done:
 _DONE = _Done()
 
 
+class LocalGroup:
+    """In-process stand-in for a process group: `world` shards live in one process (one Python
+    thread each, all on the same device) and exchange rows by device-to-device copies.  This is the
+    one-GPU form of SURVEY.md 8e's validation mode ("shards executed sequentially, exchange via
+    device copies"): every byte a rank would receive over xGMI is copied from the peer shard's
+    tensors, so the re-assembled result IS the distributed result."""
+
+    def __init__(self, world, timeout=300.0):
+        import threading
+        self.world = world
+        self._barrier = threading.Barrier(world, timeout=timeout)
+        self._box = [None] * world
+
+    def handle(self, rank):
+        return _LocalHandle(self, rank)
+
+    def abort(self):
+        self._barrier.abort()
+
+    def exchange_counts(self, rank, counts):
+        self._box[rank] = list(counts)
+        self._barrier.wait()
+        got = [self._box[p][rank] for p in range(self.world)]
+        self._barrier.wait()
+        return got
+
+    def all_to_all(self, rank, out, inp, out_splits, in_splits):
+        """out rows [sum(out_splits[:p]), +out_splits[p]) = the rows peer p addressed to `rank`."""
+        self._box[rank] = (inp, list(in_splits))
+        self._barrier.wait()
+        o = 0
+        for p in range(self.world):
+            src, splits = self._box[p]
+            b = sum(splits[:rank])
+            n = splits[rank]
+            assert n == out_splits[p], "split sizes of ranks %d and %d disagree" % (rank, p)
+            if n:
+                out[o:o + n].copy_(src[b:b + n])
+            o += n
+        if out.is_cuda:
+            torch.cuda.current_stream(out.device).synchronize()   # peers may reuse their send buffers after the barrier
+        self._barrier.wait()
+
+
+class _LocalHandle:
+    def __init__(self, group, rank):
+        self.group, self.rank = group, rank
+
+
+def run_local_shards(world, fn, timeout=300.0):
+    """Run fn(rank, group_handle) for every rank of a LocalGroup on `world` threads; returns the list
+    of results.  An exception in one shard aborts the others (no hang at the barrier)."""
+    import threading
+    grp = LocalGroup(world, timeout)
+    out, err = [None] * world, []
+
+    def body(r):
+        try:
+            out[r] = fn(r, grp.handle(r))
+        except BaseException as exc:   # noqa: BLE001 -- re-raised below
+            err.append((r, exc))
+            grp.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if err:
+        err.sort(key=lambda e: isinstance(e[1], threading.BrokenBarrierError))
+        raise err[0][1]
+    return out
+
+
 class ShardedAttention:
     def __init__(self, rank, world, bounds, src_global, dst_global, device, chunk_size=32, ops=None,
-                 group=None, emulate=False):
+                 group=None, timing_only=False):
         """src_global/dst_global: the edges whose source lies in this rank's range (any order).
-        emulate=True builds one shard without a process group: collectives are replaced by local
-        copies of the right sizes (single-GPU rehearsal of a shard's compute, bench.py
-        --emulate-world); results are then NOT the distributed result."""
+        group: a torch.distributed process group (None = default), or a LocalGroup handle (all shards
+        in this process, exchanges are device copies: exact results on one GPU).
+        timing_only=True builds ONE shard with no peers at all: exchanges become local copies of the
+        right sizes, so the shard's kernels see the right shapes and the step can be timed when the
+        other shards do not fit next to it (bench.py --emulate-world on papers100M-size shards).
+        Values involving halo rows are then meaningless and must not be checked."""
         self.rank, self.world, self.bounds, self.group = rank, world, list(bounds), group
-        self.emulate = emulate
+        self.emulate = timing_only
+        self.local = group if isinstance(group, _LocalHandle) else None
         self._buffers = {}
+        self.timers = None       # set to {} to collect per-exchange wall times (bench.py)
         self.device = torch.device(device)
         self.ops = ops
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -90,7 +169,7 @@ class ShardedAttention:
         send_counts = self._exchange_counts(self.recv_counts)
         need_local = (halo_ids - b[owner]).contiguous()       # row index inside the owner's range
         serve = torch.empty(sum(send_counts), dtype=torch.int64, device=self.device)
-        if emulate:   # pretend the peers ask for as many of our rows as we ask of theirs
+        if timing_only:   # pretend the peers ask for as many of our rows as we ask of theirs
             serve = torch.arange(sum(send_counts), device=self.device) % max(1, self.n_own)
         else:
             self._all_to_all(serve, need_local, send_counts, self.recv_counts)
@@ -103,10 +182,28 @@ class ShardedAttention:
         t_out = torch.empty_like(t_in)
         if self.world == 1 or self.emulate:
             return counts
+        if self.local is not None:
+            return self.local.group.exchange_counts(self.rank, counts)
         if t_in.is_cuda and dist.get_backend(self.group) == "gloo":
             t_in, t_out = t_in.cpu(), t_out.cpu()
         dist.all_to_all_single(t_out, t_in, group=self.group)
         return t_out.tolist()
+
+    def _timed(self, name, fn):
+        """Wall time of one exchange incl. device completion (only when self.timers is a dict: the
+        syncs it needs defeat the overlap, so bench.py measures exchanges in a separate pass)."""
+        if self.timers is None:
+            return fn()
+        import time
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        r = fn()
+        r.wait()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.timers.setdefault(name, []).append(time.perf_counter() - t0)
+        return _DONE
 
     def _all_to_all(self, out, inp, out_splits, in_splits, async_op=False):
         """Variable-size all-to-all (splits count rows).  Returns a handle whose wait() orders the
@@ -121,6 +218,9 @@ class ShardedAttention:
             if out.shape[0] > n:
                 out[n:].zero_()
             return _DONE
+        if self.local is not None:
+            self.local.group.all_to_all(self.rank, out, inp, out_splits, in_splits)
+            return _DONE
         if out.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
             o, i = out.cpu(), inp.cpu()
@@ -130,28 +230,56 @@ class ShardedAttention:
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
         return work if async_op else _DONE
 
-    def gather_halo_into(self, X_own, X_ext, async_op=False):
+    def gather_halo_into(self, X_own, X_ext, async_op=False, role="x"):
         """X_ext[:n_own] = X_own; X_ext[n_own:] = rows of X for the halo nodes, fetched from their
         owners straight into the tail of the (preallocated) extended tensor -- no concatenation.
         With async_op the exchange is only started: call wait() on the returned handle before the
         halo rows are read."""
         n_own = self.n_own
         X_ext[:n_own].copy_(X_own)
-        send = X_own[self.serve_rows].contiguous()
-        return self._all_to_all(X_ext[n_own:], send, self.recv_counts, self.send_counts, async_op)
+        send = self._pack(X_own, role)
+        return self._timed("halo_" + role, lambda: self._all_to_all(X_ext[n_own:], send, self.recv_counts,
+                                                                   self.send_counts, async_op))
 
-    def scatter_halo_grad_start(self, dX_own, dX_halo, async_op=False):
+    def _pack(self, X_own, role):
+        """Rows peers gather from -> persistent contiguous send buffer (HIP pack kernel on the GPU)."""
+        key = ("send", role, tuple(X_own.shape[1:]), X_own.dtype)
+        buf = self._buffers.get(key)
+        if buf is None:
+            buf = X_own.new_empty((int(self.serve_rows.numel()),) + tuple(X_own.shape[1:]))
+            self._buffers[key] = buf
+        if X_own.is_cuda and self.ops is None:
+            from . import _lib
+            return _lib.gather_rows(X_own.contiguous(), self.serve_rows, out=buf)
+        torch.index_select(X_own, 0, self.serve_rows, out=buf)
+        return buf
+
+    def _add_home(self, dX_own, recv):
+        """Partial gradient rows that came home += into the owners' rows (serve_rows may repeat)."""
+        if dX_own.is_cuda and self.ops is None and dX_own.is_contiguous():
+            from . import _lib
+            _lib.scatter_add_rows(dX_own, self.serve_rows, recv)
+        else:
+            dX_own.index_add_(0, self.serve_rows, recv)
+        return dX_own
+
+    def scatter_halo_grad_start(self, dX_own, dX_halo, async_op=False, role="x"):
         """Start sending the partial gradient rows of halo nodes back to their owners."""
-        recv = dX_own.new_empty((int(self.serve_rows.numel()),) + tuple(dX_own.shape[1:]))
-        handle = self._all_to_all(recv, dX_halo.contiguous(), self.send_counts, self.recv_counts, async_op)
+        key = ("recv_grad", role, tuple(dX_own.shape[1:]), dX_own.dtype)
+        recv = self._buffers.get(key)
+        if recv is None:
+            recv = dX_own.new_empty((int(self.serve_rows.numel()),) + tuple(dX_own.shape[1:]))
+            self._buffers[key] = recv
+        send = dX_halo.contiguous()
+        handle = self._timed("grad_" + role, lambda: self._all_to_all(recv, send, self.send_counts,
+                                                                      self.recv_counts, async_op))
         return handle, recv
 
-    def scatter_halo_grad(self, dX_own, dX_halo):
+    def scatter_halo_grad(self, dX_own, dX_halo, role="x"):
         """Send partial gradient rows of halo nodes back to their owners and add them there."""
-        handle, recv = self.scatter_halo_grad_start(dX_own, dX_halo)
+        handle, recv = self.scatter_halo_grad_start(dX_own, dX_halo, role=role)
         handle.wait()
-        dX_own.index_add_(0, self.serve_rows, recv)
-        return dX_own
+        return self._add_home(dX_own, recv)
 
     def _ext_buffer(self, name, like):
         """Reusable (n_own + n_halo, ...) buffer keyed by role, shape tail and dtype."""
@@ -180,8 +308,8 @@ class ShardedAttention:
         # started at once; the V rows are only awaited in front of the SpMM, so that exchange
         # runs under the SDDMM and the softmax.
         K_ext, V_ext = self._ext_buffer("K", Kd), self._ext_buffer("V", Vd)
-        wait_k = self.gather_halo_into(Kd, K_ext, async_op=True)
-        wait_v = self.gather_halo_into(Vd, V_ext, async_op=True)
+        wait_k = self.gather_halo_into(Kd, K_ext, async_op=True, role="K")
+        wait_v = self.gather_halo_into(Vd, V_ext, async_op=True, role="V")
         a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
         a8 = g.csr_args()
         wait_k.wait()
@@ -197,18 +325,27 @@ class ShardedAttention:
         exchange = self.n_halo or self.world > 1
         dV = dV_ext[:n_own]                                     # views: updated in place
         if exchange:
-            wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True)
+            wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True, role="dV")
         ds = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
         dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd, K_ext, ds)
         dK = dK_ext[:n_own]
         if exchange:
-            self.scatter_halo_grad(dK, dK_ext[n_own:])
+            self.scatter_halo_grad(dK, dK_ext[n_own:], role="dK")
             wait_dv.wait()
-            dV.index_add_(0, self.serve_rows, recv_dv)
+            self._add_home(dV, recv_dv)
         for t, gr in ((Q, dQ), (K, dK), (V, dV)):
             if t.requires_grad:
                 t.grad = gr
         return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    def halo_stats(self, row_bytes):
+        """What this rank moves per step: rows / bytes received (K and V forward) and sent back
+        (dK, dV), for bench.py's config line."""
+        return {"n_own": self.n_own, "n_halo": self.n_halo, "recv_rows_per_peer": list(self.recv_counts),
+                "send_rows_per_peer": list(self.send_counts),
+                "bytes_per_exchange_in": self.n_halo * row_bytes,
+                "bytes_per_exchange_out": int(self.serve_rows.numel()) * row_bytes,
+                "exchanges_per_step": 4}
 
     # ---- builders --------------------------------------------------------------------------------
     @classmethod
@@ -222,10 +359,14 @@ class ShardedAttention:
 
     @classmethod
     def synthetic(cls, n_per_rank, e_per_rank, world, rank, device, alpha=0.5, seed=0, chunk_size=32,
-                  ops=None, group=None, emulate=False):
+                  ops=None, group=None, timing_only=False, cut=1.0):
         """Weak-scaling bench graph: `world` equal node ranges of a Chung-Lu graph with
         world*n_per_rank nodes; each rank draws the e_per_rank edges of its own rows on its own
-        device (sources from its range, destinations from the global weight vector)."""
+        device.  Sources come from its range; a destination comes from the GLOBAL weight vector with
+        probability `cut` and from the rank's own range otherwise.  cut = 1 is a graph without any
+        locality (every rank's halo is nearly every remote node: the worst case for a node-range
+        partition); cut ~ 0.1 is what a locality-aware partition of a citation graph leaves
+        (stated in bench.py's config line)."""
         n_total = n_per_rank * world
         w = graphs.powerlaw_weights(n_total, alpha, seed, device)
         bounds = [p * n_per_rank for p in range(world + 1)]
@@ -241,6 +382,28 @@ class ShardedAttention:
             u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
             srcs.append(lo + torch.searchsorted(cdf_own, u).clamp_(max=n_per_rank - 1))
             u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
-            dsts.append(torch.searchsorted(cdf_all, u).clamp_(max=n_total - 1))
+            d_glob = torch.searchsorted(cdf_all, u).clamp_(max=n_total - 1)
+            if cut < 1.0:
+                u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
+                d_own = lo + torch.searchsorted(cdf_own, u).clamp_(max=n_per_rank - 1)
+                keep = torch.rand(m, generator=gen, device=device) < cut
+                d_glob = torch.where(keep, d_glob, d_own)
+            dsts.append(d_glob)
         return cls(rank, world, bounds, torch.cat(srcs), torch.cat(dsts), device, chunk_size, ops, group,
-                   emulate)
+                   timing_only)
+
+    @classmethod
+    def synthetic_rmat(cls, scale, e_per_rank, world, rank, device, seed=0, chunk_size=32, ops=None,
+                       group=None, timing_only=False):
+        """High-degree-row stress graph (BASELINE.json config 5): equal node ranges of an R-MAT graph
+        on 2**scale nodes; each rank draws e_per_rank edges whose sources lie in its range
+        (graphs.rmat_edges with the range's bit prefix).  NB an R-MAT graph cut into equal node
+        ranges is not edge-balanced (range 0 holds 0.76**log2(world) of the edges); weak scaling
+        needs equal work per rank, so every rank draws the same number of edges."""
+        bits = (world - 1).bit_length()
+        assert world == 1 << bits and bits <= scale, "synthetic_rmat needs a power-of-two world"
+        n_per_rank = (1 << scale) >> bits
+        bounds = [p * n_per_rank for p in range(world + 1)]
+        src, dst = graphs.rmat_edges(scale, e_per_rank, seed + 7919 * (rank + 1), device, src_prefix_bits=bits,
+                                     src_prefix=rank)
+        return cls(rank, world, bounds, src, dst, device, chunk_size, ops, group, timing_only)

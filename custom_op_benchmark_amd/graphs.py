@@ -136,13 +136,48 @@ def chung_lu_graph(n_nodes, n_edges, alpha=0.5, seed=0, chunk_size=32, device="c
     return graph_from_coo(src, dst, n_nodes, n_nodes, chunk_size)
 
 
+def rmat_edges(scale, n_edges, seed=0, device="cpu", abcd=(0.57, 0.19, 0.19, 0.05), src_prefix_bits=0,
+               src_prefix=0, batch=1 << 25):
+    """R-MAT edge list on 2**scale nodes (Graph500 parameters by default, no vertex permutation:
+    low ids are the hubs).  With src_prefix_bits > 0 the top bits of every source are fixed to
+    `src_prefix` and the matching destination bits are drawn from the conditional quadrant
+    probabilities: the edges of ONE node-range shard, generated on that shard's device."""
+    a, b, c, d = abcd
+    g = torch.Generator(device=device).manual_seed(seed)
+    srcs, dsts = [], []
+    for s0 in range(0, n_edges, batch):
+        m = min(batch, n_edges - s0)
+        src = torch.zeros(m, dtype=torch.int64, device=device)
+        dst = torch.zeros(m, dtype=torch.int64, device=device)
+        for level in range(scale):
+            u = torch.rand(m, generator=g, device=device)
+            if level < src_prefix_bits:
+                sb = (src_prefix >> (src_prefix_bits - 1 - level)) & 1
+                p_d1 = (b / (a + b)) if sb == 0 else (d / (c + d))
+                sbit = torch.full((m,), sb, dtype=torch.int64, device=device)
+                dbit = (u < p_d1).to(torch.int64)
+            else:
+                # quadrants in order a (0,0), b (0,1), c (1,0), d (1,1)
+                sbit = (u >= a + b).to(torch.int64)
+                dbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)
+            src = (src << 1) | sbit
+            dst = (dst << 1) | dbit
+        srcs.append(src); dsts.append(dst)
+    return torch.cat(srcs), torch.cat(dsts)
+
+
 SHAPES = {
     # name: (nodes, edges)  -- shape-matched synthetic stand-ins (no datasets in the image)
     "cora": (2708, 10556),
     "reddit": (232965, 114615892),
     "products": (2449029, 61859140),
     "harness": (15360, 460800),
+    # BASELINE.json configs 4 and 5: whole-graph sizes; bench.py runs ONE 1/8 shard per GPU
+    "papers100m": (111059956, 1615685872),
+    "rmat25": (1 << 25, 1 << 30),
 }
+SHARDS_OF = {"papers100m": 8, "rmat25": 8}      # the partition the multi-GPU configs are quoted on
+DEFAULT_D = {"papers100m": 128, "rmat25": 256}  # per BASELINE.json
 
 
 # ---- on-disk container (next-row N4: the reference caches its index arrays in `i.pt`,

@@ -96,9 +96,11 @@ GRAPHOP_API int graphop_tune(const char* key, int value);
  * When enabled, every hot-path kernel launch is bracketed by two hipEvents recorded on the
  * launch stream.  graphop_profile_read synchronises them, aggregates per pass tag
  * ("sddmm_fwd", "softmax_fwd", "spmm_fwd", "spmm_bwd_dedata", "spmm_bwd_dx", "softmax_bwd",
- * "sddmm_bwd_dA", "sddmm_bwd_dB", ...), clears the log and returns the number of tags. */
+ * "sddmm_bwd_dA", "sddmm_bwd_dB", ...; output zero fills and task-queue resets are recorded under
+ * "zero_fill"), clears the log and returns the number of tags. */
 typedef struct graphop_profile_rec {
-  char name[48];
+  char name[48];   /* pass tag */
+  char kernel[48]; /* device kernel family that executed it (last launch under this tag) */
   int64_t calls;
   double total_ms;
   double min_ms;
@@ -249,6 +251,16 @@ GRAPHOP_API int graphop_attention_backward(int dtype, const int64_t* row, const 
                                int64_t n_q, int64_t n_k, int64_t h, int64_t d, void* workspace,
                                int64_t workspace_bytes, const graphop_plan_t* plan_r,
                                const graphop_plan_t* plan_c, void* stream);
+
+/* ---- halo pack / unpack of the node-range sharded step (not in the reference: single GPU) --------
+ * gather_rows:      dst[i, :] = src[idx[i], :]          (send buffer of the rows peers gather from)
+ * scatter_add_rows: dst[idx[i], :] += src[i, :]         (partial gradient rows coming home; idx may
+ *                   repeat, native float atomics).  idx values must lie in [0, n_rows) (not checked:
+ *                   the caller built them from its own range, custom_op_benchmark_amd/dist.py). */
+GRAPHOP_API int graphop_gather_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
+                        int64_t n_src_rows, int64_t row_elems, void* stream);
+GRAPHOP_API int graphop_scatter_add_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
+                             int64_t n_dst_rows, int64_t row_elems, void* stream);
 
 #ifdef __cplusplus
 }

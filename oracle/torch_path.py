@@ -78,3 +78,25 @@ def attention_step_blocked(src, dst, indptr, Q, K, V, dO, n_nodes, rows_per_bloc
         dK += Kr.grad
         dV += Vr.grad
     return o, dQ, dK, dV
+
+
+def attention_step_incidence(src, dst, Q, K, V, dO, n_nodes):
+    """The harness-verbatim form (small graphs only): copy-to-edge SDDMM through sparse incidence
+    matrices, ``(th.sparse.mm(inc_x, A) * th.sparse.mm(inc_y, B)).sum(-1)`` (wrapper.py:155-157; the
+    same product MaskedMMSimple hand-differentiates, wrapper.py:57-75), the row softmax, and the
+    SpMM as ``th.sparse.mm(adj, V)`` with autograd through the sparse values (wrapper.py:274-283).
+    Returns (o, dQ, dK, dV)."""
+    E = src.numel()
+    ar = torch.arange(E)
+    one = torch.ones(E, dtype=Q.dtype)
+    inc_x = torch.sparse_coo_tensor(torch.stack([ar, src]), one, (E, Q.size(0)))
+    inc_y = torch.sparse_coo_tensor(torch.stack([ar, dst]), one, (E, K.size(0)))
+    Q = Q.detach().clone().requires_grad_(True)
+    K = K.detach().clone().requires_grad_(True)
+    V = V.detach().clone().requires_grad_(True)
+    s = (torch.sparse.mm(inc_x, Q) * torch.sparse.mm(inc_y, K)).sum(-1)
+    a = segment_softmax(src, s, n_nodes)
+    adj = torch.sparse_coo_tensor(torch.stack([src, dst]), a, (n_nodes, V.size(0)))
+    o = torch.sparse.mm(adj, V)
+    o.backward(dO)
+    return o.detach(), Q.grad, K.grad, V.grad

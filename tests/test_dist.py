@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from custom_op_benchmark_amd import graphs
-from custom_op_benchmark_amd.dist import ShardedAttention, balanced_ranges
+from custom_op_benchmark_amd.dist import ShardedAttention, balanced_ranges, run_local_shards
 
 from util import oracle_step, rand_inputs, random_graph
 
@@ -84,3 +84,41 @@ def test_single_rank_has_no_halo():
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
     for k in ("o", "dQ", "dK", "dV"):
         torch.testing.assert_close(r[k], want[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_local_group_shards_match_single_process(world):
+    """dist.LocalGroup (all shards in one process, exchanges = copies between the shards' tensors):
+    the mode the GPU tier uses to run the sharded HIP step on one GPU (tests/test_dist_gpu.py)."""
+    g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
+    inp = rand_inputs(g, 1, 16, seed=22, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+
+    def shard(rank, handle):
+        sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle,
+                                              group=handle)
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        return lo, hi, sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
+
+    for lo, hi, r in run_local_shards(world, shard):
+        for k in ("o", "dQ", "dK", "dV"):
+            torch.testing.assert_close(r[k], want[k][lo:hi], rtol=1e-4, atol=1e-5)
+
+
+def test_local_group_propagates_errors():
+    def shard(rank, handle):
+        if rank == 1:
+            raise ValueError("boom")
+        handle.group.exchange_counts(rank, [0, 0])
+    with pytest.raises(ValueError, match="boom"):
+        run_local_shards(2, shard, timeout=20.0)
+
+
+def test_rmat_shard_edges_stay_in_range():
+    from custom_op_benchmark_amd.graphs import rmat_edges
+    src, dst = rmat_edges(10, 5000, seed=1, src_prefix_bits=2, src_prefix=3)
+    assert int(src.min()) >= 768 and int(src.max()) < 1024 and int(dst.min()) >= 0 and int(dst.max()) < 1024
+    s2, d2 = rmat_edges(10, 20000, seed=2)
+    # Graph500 marginals: P(src top bit = 0) = a + b = 0.76, P(dst top bit = 0) = a + c = 0.76
+    assert abs(float((s2 < 512).float().mean()) - 0.76) < 0.02
+    assert abs(float((d2 < 512).float().mean()) - 0.76) < 0.02

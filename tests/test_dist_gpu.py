@@ -1,0 +1,90 @@
+"""GPU tier: the node-range sharded step with the HIP operators, all shards on ONE GPU.
+
+SURVEY.md 8e's validation mode: the W shards of a graph live in one process (dist.LocalGroup, one
+thread per shard), every halo exchange is a true device-to-device copy between the shards' tensors
+(HIP pack kernel -> all-to-all by copies -> HIP scatter-add kernel), and the re-assembled
+o, dQ, dK, dV, s, a must equal the single-process oracle step on the global graph.  Exercises the
+non-square n_own x (n_own + n_halo) local graphs on the HIP path, incl. the window drivers."""
+import pytest
+import torch
+
+import oracle
+from custom_op_benchmark_amd import _lib
+from custom_op_benchmark_amd.dist import ShardedAttention, run_local_shards
+
+from util import oracle_step, rand_inputs, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, g, inp, world, chunk_size=8):
+    def shard(rank, handle):
+        sh = ShardedAttention.from_global_coo(g.src.to(dev), g.dst.to(dev), g.n_src, rank, world, dev,
+                                              chunk_size=chunk_size, group=handle)
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        r = sh.step(*(inp[k][lo:hi].to(dev).contiguous() for k in ("Q", "K", "V", "dO")))
+        torch.cuda.synchronize()
+        ext_ids = torch.cat([torch.arange(lo, hi, device=dev), sh.halo_ids])
+        key = (sh.graph.src + lo) * g.n_dst + ext_ids[sh.graph.dst]
+        return dict(lo=lo, hi=hi, key=key.cpu(), n_halo=sh.n_halo, recv=sh.recv_counts,
+                    **{k: v.detach().cpu() for k, v in r.items()})
+    return run_local_shards(world, shard)
+
+
+def _check(g, want, parts):
+    got = {k: torch.zeros_like(want[k]) for k in ("o", "dQ", "dK", "dV", "s", "a")}
+    for z in parts:
+        lo, hi = z["lo"], z["hi"]
+        for k in ("o", "dQ", "dK", "dV"):
+            got[k][lo:hi] = z[k]
+        m = (g.src >= lo) & (g.src < hi)
+        order = torch.argsort(z["key"], stable=True)       # local slot order -> (src, global dst) order
+        got["s"][m] = z["s"][order]
+        got["a"][m] = z["a"][order]
+    for k in got:
+        torch.testing.assert_close(got[k], want[k], rtol=1e-4, atol=1e-5, msg=lambda msg: k + ": " + msg)
+
+
+@pytest.mark.parametrize("world,h,d", [(2, 1, 64), (3, 2, 16), (4, 1, 16)])
+def test_sharded_hip_step_matches_oracle(dev, world, h, d):
+    g = random_graph(400, 400, 12000, seed=21, chunk_size=8, zero_rows=0.1, hub=700)
+    inp = rand_inputs(g, h, d, seed=22, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    parts = _run(dev, g, inp, world)
+    assert all(z["n_halo"] > 0 and z["recv"][r] == 0 for r, z in enumerate(parts))
+    _check(g, want, parts)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hip_step_window_drivers(dev, world):
+    """Same, with the column-window drivers forced on the shards' non-square local graphs."""
+    _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 4); _lib.tune("vrow_t", 64)
+    _lib.tune("sweep_min_granule", 0); _lib.clear_plan_cache()
+    try:
+        g = random_graph(1500, 1500, 30000, seed=5, chunk_size=32, zero_rows=0.1, hub=900)
+        inp = rand_inputs(g, 1, 64, seed=6, normal=True)
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+        _lib.profile_enable(True)
+        parts = _run(dev, g, inp, world, chunk_size=32)
+        tags = set(_lib.profile_read())
+        _lib.profile_enable(False)
+        assert {"halo_pack", "halo_unpack_add"} <= tags, tags
+        _check(g, want, parts)
+    finally:
+        _lib.profile_enable(False)
+        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
+        _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+
+
+def test_pack_and_scatter_add_kernels(dev):
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for shape, dt in (((50, 64), torch.float32), ((50, 3, 5), torch.float32), ((40, 8, 16), torch.float64)):
+        X = torch.rand(shape, device=dev, generator=gen, dtype=dt)
+        idx = torch.randint(0, shape[0], (137,), device=dev, generator=gen)
+        got = _lib.gather_rows(X, idx)
+        assert torch.equal(got, X[idx])
+        acc = torch.rand(shape, device=dev, generator=gen, dtype=dt)
+        want = acc.clone().index_add_(0, idx, got)
+        _lib.scatter_add_rows(acc, idx, got)
+        torch.testing.assert_close(acc, want, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6)
+    assert _lib.gather_rows(X, idx[:0]).shape[0] == 0

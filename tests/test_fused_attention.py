@@ -82,6 +82,7 @@ def test_fused_window_passes_vs_oracle(dev, force_sweep, d, scale, k, bpc):
     """The fused window-owner passes (forced by tiny windows): rows longer than vrow_t are cut into
     pieces merged by atomics, empty rows / windows occur, non-square graph, several tasks per wave."""
     _lib.tune("attn_window_scale", scale); _lib.tune("attn_k", k); _lib.tune("attn_bpc", bpc)
+    _lib.tune("window_kb", 4 * max(1, d // 64))      # a few packed rows per window at every width
     n = 120 if d >= 512 else 1500
     g = random_graph(n, n + 41, 10 * n, seed=77 + d, chunk_size=32, zero_rows=0.15, hub=900)
     inp = rand_inputs(g, 1, d, seed=8, normal=True)

@@ -4,21 +4,25 @@ kernel family, corrected as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_
 wide 16-B/lane coalesced reads on gfx950, WRITE_SIZE (KiB) as is; separate --pmc passes.
 usage: tools/make_traffic_json.py <pmc_summary.json> <workload-tag> > profiles/pmc_traffic.json"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernels_sha  # noqa: E402  (hash of the kernel sources the counters were collected on)
 
 summ = json.load(open(sys.argv[1]))
 fam = {}
 for name, v in summ.items():
     if not name or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
-    f = re.sub(r"<.*", "", name).replace("_sweep", "").replace("_wown", "")
+    f = re.sub(r"<.*", "", name)          # the family bench.py names: k_spmm_wown_f32, k_sddmm_wown_f32, ...
     e = fam.setdefault(f, {"bytes": 0.0, "n": 0, "variants": {}})
     b = v["FETCH_SIZE"] * 2048 + v["WRITE_SIZE"] * 1024
     e["bytes"] += b; e["n"] += 1
     e["variants"][name] = {"fetch_KiB": v["FETCH_SIZE"], "write_KiB": v["WRITE_SIZE"], "hbm_bytes_per_launch": b,
                            "l2_hit_rate": v.get("l2_hit_rate")}
-out = {"workload": sys.argv[2],
+out = {"workload": sys.argv[2], "kernels_sha": kernels_sha(),
        "note": "FETCH_SIZE*2 (gfx950 wide-read correction) + WRITE_SIZE, KiB->bytes, mean over the kernel "
                "variants of the family; counters are L2 fabric-side requests, Infinity-Cache hits included; "
                "4-B id streams are uncalibrated (MI355X_MICROARCH.md, HBM)",
