@@ -5,6 +5,8 @@ __graft_entry__ as g; g.build()"`` or ``make -C custom_op_benchmark_amd/csrc``),
 not on a ROCm device, every op raises.  PyTorch is used only for device memory and the current
 stream.
 """
+import atexit
+import collections
 import ctypes
 import os
 import weakref
@@ -27,7 +29,16 @@ class PlanInfo(ctypes.Structure):
                 ("indptr_monotone", ctypes.c_int32), ("eid_identity", ctypes.c_int32),
                 ("full_coverage", ctypes.c_int32), ("row_owned", ctypes.c_int32),
                 ("has_idx32", ctypes.c_int32), ("dense_fill_pct", ctypes.c_int32),
-                ("n_dense_blocks", _c64)]
+                ("sorted_in_rows", ctypes.c_int32), ("n_dense_blocks", _c64)]
+
+
+class SweepInfo(ctypes.Structure):
+    _fields_ = [("win_cols", _c64), ("W", ctypes.c_int32), ("T", ctypes.c_int32), ("V", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
+FREE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
 class ProfileRec(ctypes.Structure):
@@ -45,6 +56,13 @@ _SIGNATURES = {
     "graphop_partition_csr_fill": [_P, _P, _c64, _c64, _c64, _P, _P, _P],
     "graphop_plan_create": [_P, _P, _P, _P, _c64, _c64, _c64, _P, ctypes.POINTER(_vp)],
     "graphop_plan_info": [_P, ctypes.POINTER(PlanInfo)],
+    "graphop_set_allocator": [ALLOC_FN, FREE_FN],
+    "graphop_plan_prepare": [_P, ctypes.c_int, _c64, _c64, _c64, ctypes.c_int, _P],
+    "graphop_plan_n_sweeps": [_P],
+    "graphop_plan_sweep_info": [_P, ctypes.c_int, ctypes.POINTER(SweepInfo)],
+    "graphop_plan_array": [_P, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_c64)],
+    "graphop_plan_import": [_P] * 4 + [ctypes.POINTER(PlanInfo)] + [_P] * 4 + [_c64] + [_P] * 4 + [ctypes.POINTER(_vp)],
+    "graphop_plan_import_sweep": [_P, ctypes.POINTER(SweepInfo), _P, _P, _P, _P],
     "graphop_maskedmm_csr_forward": [ctypes.c_int] + [_P] * 7 + [_c64] * 6 + [_P, _P],
     "graphop_maskedmm_csr_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_sparse_softmax_forward": [ctypes.c_int] + [_P] * 5 + [_c64] * 3 + [_P, _c64, _P, _P],
@@ -85,8 +103,42 @@ def lib():
         if l.graphop_abi_version() != ABI_VERSION:
             raise RuntimeError("graphop: ABI version mismatch (library %d, binding %d)"
                                % (l.graphop_abi_version(), ABI_VERSION))
+        if os.environ.get("GRAPHOP_TORCH_ALLOC", "1") != "0":
+            l.graphop_set_allocator(_ALLOC_CB, _FREE_CB)
+            atexit.register(_drop_allocator, l)
         _lib = l
     return _lib
+
+
+# Plan memory comes from torch's caching allocator (include/graphop_hip.h: graphop_set_allocator):
+# visible to torch.cuda's accounting, reclaimable, and freed stream-ordered (no device-wide stall).
+_live_blocks = {}
+
+
+def _alloc_cb(nbytes, device, stream):
+    try:
+        t = torch.empty(max(1, int(nbytes)), dtype=torch.uint8, device=torch.device("cuda", device))
+    except RuntimeError:        # out of memory: the library reports it
+        return None
+    _live_blocks[t.data_ptr()] = t
+    return t.data_ptr()
+
+
+def _free_cb(p):
+    _live_blocks.pop(p, None)
+
+
+_ALLOC_CB, _FREE_CB = ALLOC_FN(_alloc_cb), FREE_FN(_free_cb)
+
+
+def _drop_allocator(l):
+    # interpreter shutdown: plans destroyed later must not call back into Python
+    l.graphop_set_allocator(ctypes.cast(None, ALLOC_FN), ctypes.cast(None, FREE_FN))
+
+
+def plan_memory_bytes():
+    """Device bytes currently held by plans and their window structures (torch-allocated)."""
+    return sum(t.numel() for t in _live_blocks.values())
 
 
 def check(rc):
@@ -113,21 +165,82 @@ def dtype_code(t):
 
 
 # ---- plans: cached per (row, indptr, eid, indices) tensor identity ------------------------------
+_PLAN_ARRAYS = (("seg_chunk", torch.int64), ("idx32", torch.int32), ("eid32", torch.int32),
+                ("long_segs", torch.int32), ("blk_seg", torch.int32), ("seg_e0", torch.int32),
+                ("seg_row", torch.int32))
+_SWEEP_ARRAYS = ("vr_row", "wp_lo", "wp_hi")
+
+
 class Plan:
     """Owner of a graphop_plan_t*.  Holds references to the tensors it was built from."""
 
-    def __init__(self, row, indptr, eid, indices, n_index_bound):
+    def __init__(self, row, indptr, eid, indices, n_index_bound, state=None):
         self.tensors = (row, indptr, eid, indices)
         handle = _vp(0)
         with torch.cuda.device(row.device):
-            check(lib().graphop_plan_create(ptr(row), ptr(indptr), ptr(eid), ptr(indices),
-                                            row.numel(), eid.numel(), int(n_index_bound),
-                                            stream_of(row), ctypes.byref(handle)))
+            if state is None:
+                check(lib().graphop_plan_create(ptr(row), ptr(indptr), ptr(eid), ptr(indices),
+                                                row.numel(), eid.numel(), int(n_index_bound),
+                                                stream_of(row), ctypes.byref(handle)))
+            else:
+                handle = self._import(row, indptr, eid, indices, state)
         self.handle = handle
         info = PlanInfo()
         check(lib().graphop_plan_info(handle, ctypes.byref(info)))
         self.info = info
         self._finalizer = weakref.finalize(self, lib().graphop_plan_destroy, handle)
+
+    # ---- persistence (graphs.save_graph / load_graph) -------------------------------------------
+    def _array(self, name, dtype, sweep=-1):
+        p, n = _vp(0), _c64(0)
+        check(lib().graphop_plan_array(self.handle, name.encode(), sweep, ctypes.byref(p), ctypes.byref(n)))
+        if not p.value or n.value == 0:
+            return None
+        dev = self.tensors[1].device
+        out = torch.empty(n.value // torch.empty((), dtype=dtype).element_size(), dtype=dtype, device=dev)
+        with torch.cuda.device(dev):
+            torch.cuda.current_stream().synchronize()
+            _memcpy_d2d(out.data_ptr(), p.value, n.value)
+        return out.cpu()
+
+    def export_state(self):
+        """Everything needed to re-create this plan without analysing the graph: the info record,
+        the derived arrays and every window structure built so far (CPU tensors)."""
+        st = {"info": {f: getattr(self.info, f) for f, _ in PlanInfo._fields_}, "sweeps": []}
+        for name, dt in _PLAN_ARRAYS:
+            st[name] = self._array(name, dt)
+        for i in range(lib().graphop_plan_n_sweeps(self.handle)):
+            si = SweepInfo()
+            check(lib().graphop_plan_sweep_info(self.handle, i, ctypes.byref(si)))
+            sw = {"W": si.W, "T": si.T, "V": si.V, "win_cols": si.win_cols}
+            for name in _SWEEP_ARRAYS:
+                sw[name] = self._array(name, torch.int32, i)
+            st["sweeps"].append(sw)
+        return st
+
+    def _import(self, row, indptr, eid, indices, state):
+        dev = indptr.device
+        info = PlanInfo(**state["info"])
+        arrs = {name: (state.get(name).to(dev) if state.get(name) is not None else None) for name, _ in _PLAN_ARRAYS}
+        handle = _vp(0)
+        n_long = arrs["long_segs"].numel() if arrs["long_segs"] is not None else 0
+        check(lib().graphop_plan_import(ptr(row), ptr(indptr), ptr(eid), ptr(indices), ctypes.byref(info),
+                                        ptr(arrs["seg_chunk"]), ptr(arrs["idx32"]), ptr(arrs["eid32"]),
+                                        ptr(arrs["long_segs"]), n_long, ptr(arrs["blk_seg"]), ptr(arrs["seg_e0"]),
+                                        ptr(arrs["seg_row"]), stream_of(indptr), ctypes.byref(handle)))
+        for sw in state.get("sweeps", []):
+            si = SweepInfo(win_cols=sw["win_cols"], W=sw["W"], T=sw["T"], V=sw["V"], reserved=0)
+            a = [sw[name].to(dev) for name in _SWEEP_ARRAYS]
+            check(lib().graphop_plan_import_sweep(handle, ctypes.byref(si), ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                                                  stream_of(indptr)))
+        torch.cuda.current_stream(dev).synchronize()     # the staging tensors die here
+        return handle
+
+    def prepare(self, dtype, n_table_rows, h, d, fused=True):
+        """Build every cached window structure ops on (n_table_rows, h, d) tensors will use."""
+        with torch.cuda.device(self.tensors[1].device):
+            check(lib().graphop_plan_prepare(self.handle, dtype, int(n_table_rows), int(h), int(d),
+                                             1 if fused else 0, stream_of(self.tensors[1])))
 
     def __repr__(self):
         i = self.info
@@ -137,7 +250,28 @@ class Plan:
                                           i.has_idx32))
 
 
-_plan_cache = {}
+def _memcpy_d2d(dst, src, nbytes):
+    hip = _hip_runtime()
+    rc = hip.hipMemcpy(_vp(dst), _vp(src), ctypes.c_size_t(nbytes), 3)   # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError("graphop: hipMemcpy failed (%d)" % rc)
+
+
+_hip = None
+
+
+def _hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+    return _hip
+
+
+# ---- plan cache: least-recently-used, keyed by tensor identity ----------------------------------
+# Fast path: the row tensor of an orientation remembers its plans (compared by object identity and
+# version counters: no data_ptr() calls per op).  Slow path: an LRU dict keyed by storage address,
+# so equal views of the same arrays share a plan.
+_plan_cache = collections.OrderedDict()
 _PLAN_CACHE_MAX = 64
 
 
@@ -146,29 +280,61 @@ def _key(*ts):
                  for t in ts)
 
 
-def get_plan(row, indptr, eid, indices=None, n_index_bound=0):
+def _remember(row, indptr, eid, indices, plan):
+    lst = row.__dict__.setdefault("_graphop_plans", [])
+    lst.append((indptr, eid, indices, (row._version, indptr._version, eid._version,
+                                       indices._version if indices is not None else -1), plan))
+    if len(lst) > 4:
+        del lst[0]
+
+
+def get_plan(row, indptr, eid, indices=None, n_index_bound=0, state=None):
     """Plan for one CSR orientation, cached while the tensors are unchanged.  A request without
-    ``indices`` (softmax, node_mul_edge) reuses any plan of the same (row, indptr, eid)."""
+    ``indices`` (softmax, node_mul_edge) reuses any plan of the same (row, indptr, eid).
+    ``state``: an export_state() record to re-create the plan from instead of analysing the graph."""
+    lst = row.__dict__.get("_graphop_plans")
+    if lst is not None and state is None:
+        for ip, ei, ix, ver, p in lst:
+            if ip is indptr and ei is eid and (indices is None or ix is indices) and \
+                    ver[0] == row._version and ver[1] == indptr._version and ver[2] == eid._version and \
+                    (indices is None or ver[3] == indices._version):
+                if indices is not None and n_index_bound > 0 and p.info.max_index >= n_index_bound:
+                    raise RuntimeError("graphop: indices holds %d but the gathered tensor has only %d rows"
+                                       % (p.info.max_index, n_index_bound))
+                return p
     k3 = _key(row, indptr, eid)
     entry = _plan_cache.get(k3)
     if entry is None:
-        if len(_plan_cache) >= _PLAN_CACHE_MAX:
-            _plan_cache.pop(next(iter(_plan_cache)))
+        while len(_plan_cache) >= _PLAN_CACHE_MAX:
+            _plan_cache.popitem(last=False)          # least recently used
         entry = _plan_cache[k3] = {}
+    else:
+        _plan_cache.move_to_end(k3)
     if indices is None:
         p = next(iter(entry.values()), None)
         ki = None
     else:
         ki = _key(indices)
         p = entry.get(ki)
-    if p is None:
-        p = Plan(row, indptr, eid, indices, n_index_bound)
+    if p is None or state is not None:
+        p = Plan(row, indptr, eid, indices, n_index_bound, state)
         entry.pop(None, None)          # a plan with indices supersedes the index-less one
         entry[ki] = p
     elif indices is not None and n_index_bound > 0 and p.info.max_index >= n_index_bound:
         raise RuntimeError("graphop: indices holds %d but the gathered tensor has only %d rows"
                            % (p.info.max_index, n_index_bound))
+    _remember(row, indptr, eid, indices, p)
     return p
+
+
+def release_plans(*rows):
+    """Drop the plans attached to these row tensors (both cache levels); their device memory goes
+    back to torch's allocator as soon as no op holds them."""
+    for row in rows:
+        lst = row.__dict__.pop("_graphop_plans", None) or []
+        plans = {id(e[4]) for e in lst}
+        for k in [k for k, ent in _plan_cache.items() if any(id(p) in plans for p in ent.values())]:
+            del _plan_cache[k]
 
 
 def tune(key, value):
@@ -195,6 +361,9 @@ def profile_read():
 
 
 def clear_plan_cache():
+    for ent in _plan_cache.values():
+        for p in ent.values():
+            p.tensors[0].__dict__.pop("_graphop_plans", None)
     _plan_cache.clear()
 
 

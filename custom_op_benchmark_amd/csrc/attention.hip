@@ -14,15 +14,27 @@ namespace graphop {
 namespace {
 
 // resident workgroups per CU the fused kernels are compiled for: the column-major pass carries two
-// accumulators and the statistics pipeline and needs more than 128 VGPRs
-constexpr int kAttnBpcRow = 4;
-constexpr int kAttnBpcCol = 3;
+// accumulators and the statistics pipeline and needs more than 128 VGPRs; so do rows of >= 512 floats
+constexpr int attn_bpc(int NV, bool col) { return col ? (NV >= 4 ? 2 : 3) : (NV >= 2 ? 3 : 4); }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct AttnFast {
   SweepLaunch r, c;   // row-major pass (gathers K|V), column-major pass (gathers Q|dO)
 };
+
+SweepOpts attn_opts(int L, int NV, bool col, bool dry_run) {
+  const Tuning& t = tuning();
+  SweepOpts o;
+  o.row_bytes = 2 * 16LL * L * NV;
+  o.K = t.attn_k > 0 ? t.attn_k : (4 / NV > 0 ? 4 / NV : 1);
+  o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
+  o.require_owner = 1;
+  o.dry_run = dry_run ? 1 : 0;
+  const int cap = attn_bpc(NV, col);
+  o.bpc = (t.attn_bpc > 0 && t.attn_bpc < cap) ? t.attn_bpc : cap;
+  return o;
+}
 
 // Do the fused window-owner passes apply?  1 = yes (launch geometry in *out), 0 = no, < 0 = error.
 // dry_run: only decide (and build the cached window structures), take no task queue.
@@ -37,15 +49,9 @@ int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const
     return 0;
   int use_r = 0, use_c = 0;
   GO_DISPATCH_LNV((int)d, {
-    SweepOpts o;
-    o.row_bytes = 2 * 16LL * L * NV;
-    o.K = t.attn_k > 0 ? t.attn_k : (4 / NV > 0 ? 4 / NV : 1);
-    o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
-    o.require_owner = 1;
-    o.dry_run = dry_run ? 1 : 0;
-    o.bpc = (t.attn_bpc > 0 && t.attn_bpc < kAttnBpcRow) ? t.attn_bpc : kAttnBpcRow;
+    SweepOpts o = attn_opts(L, NV, false, dry_run);
     use_r = choose_sweep(plan_r, n_k, L, NV, st, &out->r, 0, true, &o);
-    o.bpc = (t.attn_bpc > 0 && t.attn_bpc < kAttnBpcCol) ? t.attn_bpc : kAttnBpcCol;
+    o = attn_opts(L, NV, true, dry_run);
     if (use_r == 1) use_c = choose_sweep(plan_c, n_q, L, NV, st, &out->c, 0, true, &o);
   });
   if (use_r < 0) return use_r;
@@ -89,7 +95,7 @@ int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gather
   const dim3 grid(sl.blocks), block(kFastBlock);
   GO_DISPATCH_LNV(F, {
     const bool off32 = n_gathered * 2 * 16LL * L * NV < (1LL << 32);
-    constexpr int BPC = COL ? kAttnBpcCol : kAttnBpcRow;
+    constexpr int BPC = attn_bpc(NV, COL);
     if (off32)
       hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, true, BPC>), grid, block, sl.lds_bytes, st,
                          sl.view, own, xt, st4, out0, out1);
@@ -102,6 +108,18 @@ int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gather
 }
 
 }  // namespace
+
+int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool col, hipStream_t st) {
+  const Tuning& t = tuning();
+  if (!t.attn_fused || t.force_generic || !plan || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024) return 0;
+  int use = 0;
+  GO_DISPATCH_LNV((int)d, {
+    SweepLaunch sl;
+    SweepOpts o = attn_opts(L, NV, col, true);
+    use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, true, &o);
+  });
+  return use;
+}
 }  // namespace graphop
 
 using namespace graphop;

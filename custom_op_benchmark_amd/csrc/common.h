@@ -46,6 +46,19 @@ inline int env_int(const char* name, int dflt) {
 
 inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
 
+// ---- device memory of plans / setup temporaries -------------------------------------------------
+// Goes through the allocator the binding registered (graphop_set_allocator: torch's caching
+// allocator in the Python binding, so plan memory is visible to / reclaimable by the framework and
+// frees are stream-ordered, no device-wide stall) or, without one, hipMalloc / hipFree.
+hipError_t go_malloc(void** p, size_t bytes, hipStream_t st);
+void go_free(void* p);
+bool go_alloc_stream_ordered();   // true: a free needs no preceding stream synchronisation
+
+// Setup work (plan / window-structure construction) allocates and synchronises: it cannot run while
+// `st` is being captured into a HIP graph.  Returns GRAPHOP_ERR_INVALID_ARGUMENT with a message
+// that names the remedy instead of letting the capture fail with an opaque HIP error.
+int check_not_capturing(hipStream_t st, const char* what);
+
 // ---- plan (host view) ---------------------------------------------------------------------------
 struct PlanStats {  // device-resident while the analysis kernels run, then copied back
   i64 unsorted;          // #positions with row[c] < row[c-1]

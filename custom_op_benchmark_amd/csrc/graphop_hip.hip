@@ -5,6 +5,7 @@
 
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,58 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+// ---- allocator hooks ---------------------------------------------------------------------------------
+static graphop_alloc_fn g_alloc = nullptr;
+static graphop_free_fn g_free = nullptr;
+static std::mutex g_alloc_mu;
+static std::set<void*> g_hooked;   // pointers that came from g_alloc (freed through g_free only)
+
+hipError_t go_malloc(void** p, size_t bytes, hipStream_t st) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  graphop_alloc_fn a;
+  { std::lock_guard<std::mutex> lk(g_alloc_mu); a = g_alloc; }
+  if (a) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void* q = a(bytes, dev, (void*)st);
+    if (!q) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_hooked.insert(q);
+    *p = q;
+    return hipSuccess;
+  }
+  return hipMalloc(p, bytes);
+}
+void go_free(void* p) {
+  if (!p) return;
+  graphop_free_fn f = nullptr;
+  bool hooked;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    hooked = g_hooked.erase(p) > 0;
+    f = g_free;
+  }
+  if (hooked) { if (f) f(p); return; }   // (allocator gone at shutdown: left to process exit)
+  (void)hipFree(p);
+}
+bool go_alloc_stream_ordered() {
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  return g_alloc != nullptr;
+}
+
+int check_not_capturing(hipStream_t st, const char* what) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    set_error("%s would allocate and synchronise while the stream is being captured into a HIP graph: "
+              "build it first (graphop_plan_create / graphop_plan_prepare, Python: graphop.prepare(graph, h, d)) "
+              "and capture afterwards", what);
+    return GRAPHOP_ERR_INVALID_ARGUMENT;
+  }
+  (void)hipGetLastError();
+  return GRAPHOP_OK;
+}
 
 // ---- optional per-kernel timing (hipEvents on the launch stream; off by default) -----------------
 struct ProfRec { const char* name; const char* kernel; hipEvent_t t0, t1; };
@@ -150,7 +203,8 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   if (t.sweep_k <= 0 && !(opts && opts->K > 0) && !pi.eid_identity && t.sweep_mode == 1 && !force_windows && K > 1) K /= 2;
   if (K > L) K = L;
   const int gpb = kFastBlock / L;
-  const int bpc_req = (opts && opts->bpc > 0) ? opts->bpc : t.sweep_bpc;
+  const int bpc_req = (opts && opts->bpc > 0) ? (opts->bpc < t.sweep_bpc || opts->window_scale > 0 ? opts->bpc : t.sweep_bpc)
+                                              : t.sweep_bpc;
   const int bpc = bpc_req < 1 ? 1 : (bpc_req > kSweepBlocksPerCu ? kSweepBlocksPerCu : bpc_req);
   int T = t.vrow_t;
   if (T <= 0) {
@@ -235,7 +289,9 @@ template <int L, int NV>
 int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
                     const void* B, void* y, i64 h, int d4, hipStream_t st) {
   SweepLaunch sl;
-  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl);
+  SweepOpts so;
+  so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
   if (use != 1) return use;
   ProfScope prof(tag, st, sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
   const bool id = plan->info.eid_identity != 0;
@@ -280,7 +336,9 @@ inline int transpose_scalars(const graphop_plan* plan, const graphop_plan* other
   if (Ws < 2) Ws = 2;
   if (Ws > t.max_windows) Ws = t.max_windows;
   SweepLaunch sl;
-  const int use = choose_sweep(other, n_other_cols, 16, 1, st, &sl, (int)Ws);
+  SweepOpts so;
+  so.bpc = sweep_bpc(1, true, false);
+  const int use = choose_sweep(other, n_other_cols, 16, 1, st, &sl, (int)Ws, false, &so);
   if (use != 1) return use;
   ProfScope prof("transpose_scalars", st);
   hipLaunchKernelGGL((k_scatter_scalars_sweep<16>), dim3(sl.blocks), dim3(kFastBlock), 0, st, sl.view,
@@ -294,7 +352,9 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
                    const void* X, void* out, i64 h, int d4, const graphop_plan* other,
                    i64 n_other_cols, hipStream_t st) {
   SweepLaunch sl;
-  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true);
+  SweepOpts so;
+  so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &so);
   if (use != 1) return use;
   bool id = plan->info.eid_identity != 0;
   const float* ww = (const float*)w;
@@ -681,6 +741,14 @@ int graphop_tune(const char* key, int value) {
   return GRAPHOP_ERR_INVALID_ARGUMENT;
 }
 
+int graphop_set_allocator(graphop_alloc_fn alloc_fn, graphop_free_fn free_fn) {
+  GO_CHECK_ARG((alloc_fn == nullptr) == (free_fn == nullptr), "set_allocator: give both callbacks or neither");
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  g_alloc = alloc_fn;
+  g_free = free_fn;
+  return GRAPHOP_OK;
+}
+
 int graphop_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
@@ -753,6 +821,7 @@ int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t
                (eid != nullptr || n_edges == 0), "plan_create: NULL pointer");
   GO_CHECK_ARG(n_chunks >= 0 && n_chunks < 0x7fffffffLL && n_edges >= 0,
                "plan_create: size out of range");
+  GO_TRY(check_not_capturing((hipStream_t)stream, "plan_create"));
   graphop_plan* p = (graphop_plan*)calloc(1, sizeof(graphop_plan));
   GO_CHECK_ARG(p != nullptr, "plan_create: out of host memory");
   p->row = row; p->indptr = indptr; p->eid = eid; p->indices = indices;
@@ -775,18 +844,111 @@ int graphop_plan_info(const graphop_plan_t* plan, graphop_plan_info_t* info_out)
   return GRAPHOP_OK;
 }
 
+int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, int64_t h, int64_t d,
+                         int fused, void* stream) {
+  GO_CHECK_ARG(plan != nullptr && n_table_rows >= 0 && h >= 1 && d >= 0, "plan_prepare: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (!fast_ok(dtype, h, d, plan->info.n_edges, n_table_rows)) return GRAPHOP_OK;   // generic kernels: nothing cached
+  int rc = 0;
+  GO_DISPATCH_LNV((int)(h * d), {
+    SweepLaunch sl;
+    SweepOpts o;
+    o.dry_run = 1;
+    o.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+    rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/false, &o);
+    if (rc >= 0) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &o);
+  });
+  if (rc < 0) return -rc;
+  if (fused && h == 1) {
+    // the plan serves as the row-major side or as the column-major side of the fused passes: both
+    // use the same window geometry but may differ in the resident-grid term of the piece length
+    rc = attn_prepare_plan(plan, n_table_rows, d, false, st);
+    if (rc >= 0) rc = attn_prepare_plan(plan, n_table_rows, d, true, st);
+    if (rc < 0) return -rc;
+  }
+  return GRAPHOP_OK;
+}
+
+int graphop_plan_n_sweeps(const graphop_plan_t* plan) { return plan ? plan_n_sweeps(plan) : 0; }
+
+int graphop_plan_sweep_info(const graphop_plan_t* plan, int sweep, graphop_sweep_info_t* out) {
+  GO_CHECK_ARG(plan && out, "plan_sweep_info: NULL pointer");
+  const Sweep* s = plan_sweep_at(plan, sweep);
+  GO_CHECK_ARG(s != nullptr, "plan_sweep_info: no window structure %d", sweep);
+  out->win_cols = s->win_cols; out->W = s->W; out->T = s->T; out->V = s->V; out->reserved = 0;
+  return GRAPHOP_OK;
+}
+
+int graphop_plan_array(const graphop_plan_t* plan, const char* name, int sweep, const void** ptr,
+                       int64_t* bytes) {
+  GO_CHECK_ARG(plan && name && ptr && bytes, "plan_array: NULL pointer");
+  *ptr = nullptr; *bytes = 0;
+  const graphop_plan_info_t& in = plan->info;
+  auto give = [&](const void* p, size_t n) { if (p) { *ptr = p; *bytes = (int64_t)n; } return GRAPHOP_OK; };
+  if (sweep >= 0) {
+    const Sweep* s = plan_sweep_at(plan, sweep);
+    GO_CHECK_ARG(s != nullptr, "plan_array: no window structure %d", sweep);
+    if (!strcmp(name, "vr_row")) return give(s->vr_row, sizeof(int) * (size_t)s->V);
+    if (!strcmp(name, "wp_lo")) return give(s->wp_lo, sizeof(int) * (size_t)s->V * s->W);
+    if (!strcmp(name, "wp_hi")) return give(s->wp_hi, sizeof(int) * (size_t)s->V * s->W);
+  } else {
+    if (!strcmp(name, "seg_chunk")) return give(plan->seg_chunk, sizeof(int64_t) * (size_t)(in.n_segments + 1));
+    if (!strcmp(name, "idx32")) return give(plan->idx32, sizeof(int32_t) * (size_t)in.n_edges);
+    if (!strcmp(name, "eid32")) return give(plan->eid32, sizeof(int32_t) * (size_t)in.n_edges);
+    if (!strcmp(name, "long_segs")) return give(plan->long_segs, sizeof(int32_t) * (size_t)plan->n_long);
+    if (!strcmp(name, "blk_seg")) return give(plan->blk_seg, sizeof(int32_t) * (size_t)(in.n_dense_blocks + 1));
+    if (!strcmp(name, "seg_e0")) return give(plan->seg_e0, sizeof(int32_t) * (size_t)(in.n_segments + 1));
+    if (!strcmp(name, "seg_row")) return give(plan->seg_row, sizeof(int32_t) * (size_t)in.n_segments);
+  }
+  set_error("plan_array: unknown array '%s'", name);
+  return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
+int graphop_plan_import(const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                        const int64_t* indices, const graphop_plan_info_t* info,
+                        const int64_t* seg_chunk, const int32_t* idx32, const int32_t* eid32,
+                        const int32_t* long_segs, int64_t n_long, const int32_t* blk_seg,
+                        const int32_t* seg_e0, const int32_t* seg_row, void* stream,
+                        graphop_plan_t** plan_out) {
+  GO_CHECK_ARG(plan_out && info && indptr, "plan_import: NULL pointer");
+  *plan_out = nullptr;
+  GO_CHECK_ARG(info->n_chunks >= 0 && info->n_edges >= 0 && info->n_segments >= 0 && n_long >= 0,
+               "plan_import: bad sizes");
+  GO_TRY(check_not_capturing((hipStream_t)stream, "plan_import"));
+  graphop_plan* p = (graphop_plan*)calloc(1, sizeof(graphop_plan));
+  GO_CHECK_ARG(p != nullptr, "plan_import: out of host memory");
+  p->row = row; p->indptr = indptr; p->eid = eid; p->indices = indices;
+  p->info = *info;
+  (void)hipGetDevice(&p->device);
+  plan_init_sweeps(p);
+  const int rc = plan_import_arrays(p, (const i64*)seg_chunk, idx32, eid32, long_segs, n_long, blk_seg, seg_e0,
+                                    seg_row, (hipStream_t)stream);
+  if (rc != GRAPHOP_OK) { graphop_plan_destroy(p); return rc; }
+  *plan_out = p;
+  return GRAPHOP_OK;
+}
+
+int graphop_plan_import_sweep(graphop_plan_t* plan, const graphop_sweep_info_t* info,
+                              const int32_t* vr_row, const int32_t* wp_lo, const int32_t* wp_hi,
+                              void* stream) {
+  GO_CHECK_ARG(plan && info, "plan_import_sweep: NULL pointer");
+  GO_TRY(check_not_capturing((hipStream_t)stream, "plan_import_sweep"));
+  return plan_import_sweep(plan, info->W, info->win_cols, info->T, info->V, vr_row, wp_lo, wp_hi,
+                           (hipStream_t)stream);
+}
+
 void graphop_plan_destroy(graphop_plan_t* plan) {
   if (!plan) return;
   plan_free_sweeps(plan);
-  if (plan->seg_chunk) (void)hipFree(plan->seg_chunk);
-  if (plan->idx32) (void)hipFree(plan->idx32);
-  if (plan->eid32) (void)hipFree(plan->eid32);
-  if (plan->long_segs) (void)hipFree(plan->long_segs);
-  if (plan->inv32) (void)hipFree(plan->inv32);
-  if (plan->scalar_scratch) (void)hipFree(plan->scalar_scratch);
-  if (plan->blk_seg) (void)hipFree(plan->blk_seg);
-  if (plan->seg_e0) (void)hipFree(plan->seg_e0);
-  if (plan->seg_row) (void)hipFree(plan->seg_row);
+  if (plan->seg_chunk) go_free(plan->seg_chunk);
+  if (plan->idx32) go_free(plan->idx32);
+  if (plan->eid32) go_free(plan->eid32);
+  if (plan->long_segs) go_free(plan->long_segs);
+  if (plan->inv32) go_free(plan->inv32);
+  if (plan->scalar_scratch) go_free(plan->scalar_scratch);
+  if (plan->blk_seg) go_free(plan->blk_seg);
+  if (plan->seg_e0) go_free(plan->seg_e0);
+  if (plan->seg_row) go_free(plan->seg_row);
   free(plan);
 }
 

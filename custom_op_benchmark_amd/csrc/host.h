@@ -116,6 +116,17 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
                  SweepLaunch* out, int force_windows = 0, bool accumulating = false,
                  const SweepOpts* opts = nullptr);
 
+int plan_n_sweeps(const graphop_plan* p);
+const Sweep* plan_sweep_at(const graphop_plan* p, int i);
+int plan_import_arrays(graphop_plan* p, const i64* seg_chunk, const int32_t* idx32, const int32_t* eid32,
+                       const int32_t* long_segs, i64 n_long, const int32_t* blk_seg,
+                       const int32_t* seg_e0, const int32_t* seg_row, hipStream_t st);
+int plan_import_sweep(graphop_plan* p, int W, i64 win_cols, int T, int V, const int32_t* vr_row,
+                      const int32_t* wp_lo, const int32_t* wp_hi, hipStream_t st);
+void plan_init_sweeps(graphop_plan*);
+// the fused attention passes' window structure for ONE orientation (attention.hip); dry run
+int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool col, hipStream_t st);
+
 int softmax_forward_stats(int dtype, const i64* row, const i64* indptr, const i64* eid, const void* x,
                           void* y, i64 C, i64 E, i64 h, void* ws, i64 ws_rows,
                           const graphop_plan* plan, hipStream_t st, void* stats);

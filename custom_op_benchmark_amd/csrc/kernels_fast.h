@@ -580,8 +580,15 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
 // whose neighbour ids lie in [w*win_cols, (w+1)*win_cols).  A row longer than T slots is cut into
 // P pieces that each take 1/P of the row's slots in EVERY window.  Group g of round r owns vrows
 // [(r*n_groups + g)*K, +K).  LDS holds the K rows (A rows / partial sums) of every group.
-constexpr int kSweepBlocksPerCu = 4;   // co-resident 256-thread workgroups per CU the sweep kernels
-                                       // are compiled for (<= 128 VGPRs, 32 KB LDS each)
+constexpr int kSweepBlocksPerCu = 4;   // most co-resident 256-thread workgroups per CU any sweep kernel
+                                       // is compiled for (<= 128 VGPRs, 32 KB LDS each)
+// Resident workgroups per CU a given instantiation is compiled for (its __launch_bounds__ and the
+// grid the host launches): the one-head 16..512-float rows fit 128 VGPRs without spilling; rows of
+// 1024 floats (NV = 4), per-head weights (H1 = false: a weight register per slot and float4) and
+// the vrow-owner order (LDS partial sums + pacer state) get 168.
+__host__ __device__ constexpr int sweep_bpc(int NV, bool H1, bool owner) {
+  return (owner && H1 && NV < 4) ? 4 : 3;
+}
 struct SweepView {
   const int* wp_lo;   // [W * V]
   const int* wp_hi;   // [W * V]
@@ -713,7 +720,7 @@ __device__ __forceinline__ int sweep_prefetch(const SweepView& s, const float* t
 __device__ __forceinline__ void sweep_prefetch_retire(int v) { asm volatile("; prefetched %0" ::"v"(v)); }
 
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
-__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f32(
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, false)) void k_sddmm_sweep_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
     int h, int d4) {
   extern __shared__ float4 lds[];
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_sweep_f
 }
 
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
-__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_sweep_f32(
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, false)) void k_spmm_sweep_f32(
     SweepView s, const float* __restrict__ wgt, const float* __restrict__ X,
     float* __restrict__ out, int h, int d4) {
   extern __shared__ float4 lds[];
@@ -913,7 +920,7 @@ struct WownTask {
 // Task pipeline of both kernels: the id of task i+2 is being dequeued and the bounds of task i+1
 // are being fetched while task i runs, so a task starts with its bounds in registers.
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
-__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f32(
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_sddmm_wown_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y,
     int h, int d4) {
   extern __shared__ float4 lds[];
@@ -951,7 +958,7 @@ __global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_sddmm_wown_f3
 }
 
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32>
-__global__ __launch_bounds__(kFastBlock, kSweepBlocksPerCu) void k_spmm_wown_f32(
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_spmm_wown_f32(
     SweepView s, const float* __restrict__ wgt, const float* __restrict__ X,
     float* __restrict__ out, int h, int d4) {
   constexpr int GW = kWave / L;
@@ -1277,7 +1284,9 @@ __device__ __forceinline__ void softmax_bwd_seg_body(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
     T* __restrict__ dx, i64 n_seg, int h, i64 long_len, i64 block) {
-  constexpr int R = kSoftmaxCacheBwd;
+  // gathered through eid every cached item carries its own 64-bit offset: 8 per lane fit the
+  // register file, 32 spilled (the identity form walks one base pointer with immediate offsets)
+  constexpr int R = EID_ID ? kSoftmaxCacheBwd : 8;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;

@@ -272,7 +272,7 @@ __global__ void k_blk_same(const i64* __restrict__ seg_chunk, const i64* __restr
 
 struct DevBuf {  // frees on scope exit (setup path only)
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { go_free(p); }
 };
 
 }  // namespace
@@ -284,9 +284,9 @@ int partition_count(const i64* indptr, i64 n_rows, i64 chunk, i64* first, hipStr
   size_t tmp_bytes = 0;
   GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, first, first, (int)(n_rows + 1), st));
   DevBuf tmp;
-  GO_HIP(hipMalloc(&tmp.p, tmp_bytes ? tmp_bytes : 16));
+  GO_HIP(go_malloc(&tmp.p, tmp_bytes ? tmp_bytes : 16, st));
   GO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, first, first, (int)(n_rows + 1), st));
-  GO_HIP(hipStreamSynchronize(st));  // tmp is freed on return
+  if (!go_alloc_stream_ordered()) GO_HIP(hipStreamSynchronize(st));  // tmp is freed on return
   return GRAPHOP_OK;
 }
 
@@ -308,7 +308,7 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_det
   const i64* indices = (const i64*)p->indices;
 
   DevBuf d_stats, d_head, d_pos, d_tmp;
-  GO_HIP(hipMalloc(&d_stats.p, sizeof(PlanStats)));
+  GO_HIP(go_malloc(&d_stats.p, sizeof(PlanStats), st));
   PlanStats init;
   memset(&init, 0, sizeof(init));
   init.max_row = -1;
@@ -316,17 +316,17 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_det
   GO_HIP(hipMemcpyAsync(d_stats.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
   PlanStats* stats = (PlanStats*)d_stats.p;
 
-  GO_HIP(hipMalloc((void**)&p->seg_chunk, sizeof(i64) * (size_t)(C + 1)));
+  GO_HIP(go_malloc((void**)&p->seg_chunk, sizeof(i64) * (size_t)(C + 1), st));
   if (C > 0) {
-    GO_HIP(hipMalloc(&d_head.p, sizeof(int) * (size_t)C));
-    GO_HIP(hipMalloc(&d_pos.p, sizeof(i64) * (size_t)C));
+    GO_HIP(go_malloc(&d_head.p, sizeof(int) * (size_t)C, st));
+    GO_HIP(go_malloc(&d_pos.p, sizeof(i64) * (size_t)C, st));
     hipLaunchKernelGGL(k_plan_chunks, dim3(grid_for(C, kBlock, 4096)), dim3(kBlock), 0, st, row,
                        indptr, C, E, (int*)d_head.p, stats);
     GO_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
     GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)d_head.p, (i64*)d_pos.p,
                                             (int)C, st));
-    GO_HIP(hipMalloc(&d_tmp.p, tmp_bytes ? tmp_bytes : 16));
+    GO_HIP(go_malloc(&d_tmp.p, tmp_bytes ? tmp_bytes : 16, st));
     GO_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, (int*)d_head.p, (i64*)d_pos.p,
                                             (int)C, st));
     hipLaunchKernelGGL(k_plan_fill_heads, dim3(grid_for(C, kBlock, 4096)), dim3(kBlock), 0, st,
@@ -394,9 +394,9 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_det
   if (info.row_owned && info.max_segment_len > kLongSegment && info.n_segments < 0x7fffffffLL) {
     const int cap = (int)(E / kLongSegment + 1);
     DevBuf d_cnt;
-    GO_HIP(hipMalloc(&d_cnt.p, sizeof(int)));
+    GO_HIP(go_malloc(&d_cnt.p, sizeof(int), st));
     GO_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(int), st));
-    GO_HIP(hipMalloc((void**)&p->long_segs, sizeof(int) * (size_t)cap));
+    GO_HIP(go_malloc((void**)&p->long_segs, sizeof(int) * (size_t)cap, st));
     hipLaunchKernelGGL(k_plan_long_segs, dim3(grid_for(info.n_segments, kBlock, 4096)), dim3(kBlock),
                        0, st, (const i64*)p->seg_chunk, indptr, info.n_segments, (i64)kLongSegment,
                        p->long_segs, cap, (int*)d_cnt.p);
@@ -408,6 +408,7 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_det
   }
 
   p->sorted_in_rows = 0;
+  info.sorted_in_rows = 0;
   if (C > 0 && indices && info.row_owned) {
     hipLaunchKernelGGL(k_plan_sorted_ids, dim3(grid_for(C, kBlock, 8192)), dim3(kBlock), 0, st,
                        row, indptr, indices, C, stats);
@@ -415,19 +416,20 @@ int plan_build(graphop_plan* p, i64 n_index_bound, hipStream_t st, int dense_det
     GO_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
     GO_HIP(hipStreamSynchronize(st));
     p->sorted_in_rows = h.unsorted_ids == 0;
+    info.sorted_in_rows = p->sorted_in_rows;
   }
 
   // 32-bit mirrors of the slot arrays (halves index traffic of every pass)
   const bool want32 = env_int("GRAPHOP_IDX32", 1) != 0;
   if (want32 && E > 0 && E < 0x7fffffffLL && h.max_index < 0x7fffffffLL) {
     if (indices) {
-      GO_HIP(hipMalloc((void**)&p->idx32, sizeof(int32_t) * (size_t)E));
+      GO_HIP(go_malloc((void**)&p->idx32, sizeof(int32_t) * (size_t)E, st));
       hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, indices,
                          p->idx32, E);
       GO_LAUNCH_CHECK();
     }
     if (!info.eid_identity) {
-      GO_HIP(hipMalloc((void**)&p->eid32, sizeof(int32_t) * (size_t)E));
+      GO_HIP(go_malloc((void**)&p->eid32, sizeof(int32_t) * (size_t)E, st));
       hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, eid,
                          p->eid32, E);
       GO_LAUNCH_CHECK();
@@ -452,12 +454,12 @@ int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
     return GRAPHOP_OK;
   DevBuf same, cnt;
   int32_t *seg_e0 = nullptr, *seg_row = nullptr;
-  GO_HIP(hipMalloc(&same.p, (size_t)S));
-  GO_HIP(hipMalloc(&cnt.p, 2 * sizeof(unsigned long long)));   // [0] segments equal to their predecessor, [1] empty segments
+  GO_HIP(go_malloc(&same.p, (size_t)S, st));
+  GO_HIP(go_malloc(&cnt.p, 2 * sizeof(unsigned long long), st));   // [0] segments equal to their predecessor, [1] empty segments
   GO_HIP(hipMemsetAsync(cnt.p, 0, 2 * sizeof(unsigned long long), st));
-  if (hipMalloc((void**)&seg_e0, sizeof(int32_t) * (size_t)(S + 1)) != hipSuccess ||
-      hipMalloc((void**)&seg_row, sizeof(int32_t) * (size_t)S) != hipSuccess) {
-    (void)hipFree(seg_e0); (void)hipFree(seg_row);
+  if (go_malloc((void**)&seg_e0, sizeof(int32_t) * (size_t)(S + 1), st) != hipSuccess ||
+      go_malloc((void**)&seg_row, sizeof(int32_t) * (size_t)S, st) != hipSuccess) {
+    go_free(seg_e0); go_free(seg_row);
     return GRAPHOP_OK;   // optional structure: carry on without it
   }
   hipLaunchKernelGGL(k_blk_same, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
@@ -489,12 +491,12 @@ int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
     }
   }
   if (keep) {
-    keep = hipMalloc((void**)&p->blk_seg, sizeof(int32_t) * blk.size()) == hipSuccess &&
+    keep = go_malloc((void**)&p->blk_seg, sizeof(int32_t) * blk.size(), st) == hipSuccess &&
            hipMemcpy(p->blk_seg, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice) == hipSuccess;
   }
   if (!keep) {
-    (void)hipFree(seg_e0); (void)hipFree(seg_row);
-    if (p->blk_seg) { (void)hipFree(p->blk_seg); p->blk_seg = nullptr; }
+    go_free(seg_e0); go_free(seg_row);
+    if (p->blk_seg) { go_free(p->blk_seg); p->blk_seg = nullptr; }
     info.dense_fill_pct = 0;
     return GRAPHOP_OK;
   }
@@ -512,13 +514,17 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   for (auto& s : *vec)
     if (s.W == W && s.win_cols == win_cols && s.T == T) { *out = &s; return GRAPHOP_OK; }
   GO_CHECK_ARG(vec->size() < 16, "plan_get_sweep: too many window geometries for one plan");
+  {
+    const int rc_cap = check_not_capturing(st, "building the column-window structure of a plan");
+    if (rc_cap != GRAPHOP_OK) return rc_cap;
+  }
   const i64 S = p->info.n_segments, E = p->info.n_edges;
   GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E < 0x7fffffffLL && S > 0,
                "plan_get_sweep: plan is not sweepable");
   const i64* indptr = (const i64*)p->indptr;
   DevBuf seg_eptr, first, vr_seg, vr_ptr;
-  GO_HIP(hipMalloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1)));
-  GO_HIP(hipMalloc(&first.p, sizeof(i64) * (size_t)(S + 1)));
+  GO_HIP(go_malloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1), st));
+  GO_HIP(go_malloc(&first.p, sizeof(i64) * (size_t)(S + 1), st));
   hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
                      (const i64*)p->seg_chunk, indptr, S, (i64*)seg_eptr.p);
   GO_LAUNCH_CHECK();
@@ -528,13 +534,13 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   GO_HIP(hipMemcpyAsync(&V, (i64*)first.p + S, sizeof(i64), hipMemcpyDeviceToHost, st));
   GO_HIP(hipStreamSynchronize(st));
   GO_CHECK_ARG(V > 0 && V < 0x7fffffffLL && V * (W + 1) < (i64)1 << 40, "plan_get_sweep: size");
-  GO_HIP(hipMalloc(&vr_seg.p, sizeof(i64) * (size_t)V));
-  GO_HIP(hipMalloc(&vr_ptr.p, sizeof(i64) * (size_t)(V + 1)));
+  GO_HIP(go_malloc(&vr_seg.p, sizeof(i64) * (size_t)V, st));
+  GO_HIP(go_malloc(&vr_ptr.p, sizeof(i64) * (size_t)(V + 1), st));
   rc = partition_fill((const i64*)seg_eptr.p, (const i64*)first.p, S, T, V, (i64*)vr_seg.p,
                       (i64*)vr_ptr.p, st);
   if (rc != GRAPHOP_OK) return rc;
   DevBuf rw;
-  GO_HIP(hipMalloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1))));
+  GO_HIP(go_malloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1)), st));
   hipLaunchKernelGGL(k_sweep_row_windows, dim3(grid_for(S * (W + 1), kBlock, 16384)), dim3(kBlock),
                      0, st, (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, win_cols,
                      (int*)rw.p);
@@ -542,13 +548,13 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   Sweep s;
   s.W = W; s.win_cols = win_cols; s.T = T; s.V = (int)V;
   const size_t wp_bytes = sizeof(int) * (size_t)(V * W);
-  if (hipMalloc((void**)&s.vr_row, sizeof(int) * (size_t)V) != hipSuccess ||
-      hipMalloc((void**)&s.wp_lo, wp_bytes) != hipSuccess ||
-      hipMalloc((void**)&s.wp_hi, wp_bytes) != hipSuccess ||
-      hipMalloc((void**)&s.sync, sizeof(int) * kSweepSyncInts) != hipSuccess ||
-      hipMalloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts) != hipSuccess) {
-    (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
-    (void)hipFree(s.queues);
+  if (go_malloc((void**)&s.vr_row, sizeof(int) * (size_t)V, st) != hipSuccess ||
+      go_malloc((void**)&s.wp_lo, wp_bytes, st) != hipSuccess ||
+      go_malloc((void**)&s.wp_hi, wp_bytes, st) != hipSuccess ||
+      go_malloc((void**)&s.sync, sizeof(int) * kSweepSyncInts, st) != hipSuccess ||
+      go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync);
+    go_free(s.queues);
     set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
     return GRAPHOP_ERR_HIP;
   }
@@ -572,8 +578,8 @@ void plan_free_sweeps(graphop_plan* p) {
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
     for (auto& s : *vec) {
-      (void)hipFree(s.vr_row); (void)hipFree(s.wp_lo); (void)hipFree(s.wp_hi); (void)hipFree(s.sync);
-      (void)hipFree(s.queues);
+      go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync);
+      go_free(s.queues);
     }
     delete vec;
   }
@@ -587,19 +593,93 @@ void plan_init_sweeps(graphop_plan* p) {
   p->sweep_mu = new std::mutex();
 }
 
+// ---- persistence: read a plan's arrays out / re-create a plan from them ------------------------------
+int plan_n_sweeps(const graphop_plan* p) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  return (int)((std::vector<Sweep>*)p->sweeps)->size();
+}
+const Sweep* plan_sweep_at(const graphop_plan* p, int i) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  auto* vec = (std::vector<Sweep>*)p->sweeps;
+  return (i >= 0 && i < (int)vec->size()) ? &(*vec)[i] : nullptr;
+}
+
+static int copy_in(void** dst, const void* src, size_t bytes, hipStream_t st) {
+  *dst = nullptr;
+  if (!src || bytes == 0) return GRAPHOP_OK;
+  GO_HIP(go_malloc(dst, bytes, st));
+  GO_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, st));
+  return GRAPHOP_OK;
+}
+
+int plan_import_arrays(graphop_plan* p, const i64* seg_chunk, const int32_t* idx32, const int32_t* eid32,
+                       const int32_t* long_segs, i64 n_long, const int32_t* blk_seg,
+                       const int32_t* seg_e0, const int32_t* seg_row, hipStream_t st) {
+  const graphop_plan_info_t& in = p->info;
+  int rc;
+  if ((rc = copy_in((void**)&p->seg_chunk, seg_chunk, sizeof(i64) * (size_t)(in.n_segments + 1), st))) return rc;
+  GO_CHECK_ARG(p->seg_chunk != nullptr, "plan_import: seg_chunk is required");
+  if ((rc = copy_in((void**)&p->idx32, idx32, sizeof(int32_t) * (size_t)in.n_edges, st))) return rc;
+  if ((rc = copy_in((void**)&p->eid32, eid32, sizeof(int32_t) * (size_t)in.n_edges, st))) return rc;
+  if ((rc = copy_in((void**)&p->long_segs, long_segs, sizeof(int32_t) * (size_t)n_long, st))) return rc;
+  p->n_long = p->long_segs ? n_long : 0;
+  if (in.n_dense_blocks > 0 && blk_seg && seg_e0 && seg_row) {
+    if ((rc = copy_in((void**)&p->blk_seg, blk_seg, sizeof(int32_t) * (size_t)(in.n_dense_blocks + 1), st))) return rc;
+    if ((rc = copy_in((void**)&p->seg_e0, seg_e0, sizeof(int32_t) * (size_t)(in.n_segments + 1), st))) return rc;
+    if ((rc = copy_in((void**)&p->seg_row, seg_row, sizeof(int32_t) * (size_t)in.n_segments, st))) return rc;
+  } else {
+    p->info.n_dense_blocks = 0;
+    p->info.dense_fill_pct = 0;
+  }
+  p->sorted_in_rows = in.sorted_in_rows;
+  p->info.has_idx32 = p->idx32 != nullptr;
+  return GRAPHOP_OK;
+}
+
+int plan_import_sweep(graphop_plan* p, int W, i64 win_cols, int T, int V, const int32_t* vr_row,
+                      const int32_t* wp_lo, const int32_t* wp_hi, hipStream_t st) {
+  auto* vec = (std::vector<Sweep>*)p->sweeps;
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  for (auto& s : *vec)
+    if (s.W == W && s.win_cols == win_cols && s.T == T) return GRAPHOP_OK;   // already there
+  GO_CHECK_ARG(vec->size() < 16, "plan_import_sweep: too many window geometries for one plan");
+  GO_CHECK_ARG(W >= 1 && V >= 1 && vr_row && wp_lo && wp_hi, "plan_import_sweep: bad arguments");
+  Sweep s;
+  s.W = W; s.win_cols = win_cols; s.T = T; s.V = V;
+  int rc;
+  if ((rc = copy_in((void**)&s.vr_row, vr_row, sizeof(int) * (size_t)V, st)) ||
+      (rc = copy_in((void**)&s.wp_lo, wp_lo, sizeof(int) * (size_t)V * W, st)) ||
+      (rc = copy_in((void**)&s.wp_hi, wp_hi, sizeof(int) * (size_t)V * W, st))) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
+    return rc;
+  }
+  if (go_malloc((void**)&s.sync, sizeof(int) * kSweepSyncInts, st) != hipSuccess ||
+      go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync); go_free(s.queues);
+    set_error("plan_import_sweep: out of device memory");
+    return GRAPHOP_ERR_HIP;
+  }
+  vec->push_back(s);
+  return GRAPHOP_OK;
+}
+
 // Inverse of eid (slot of every edge id) + a float scratch of n_edges values, built on first use.
 // Returns GRAPHOP_OK with p->inv_state == 1 when available, -1 when eid is not a permutation.
 int plan_get_inverse(graphop_plan* p, hipStream_t st) {
   auto* mu = (std::mutex*)p->sweep_mu;
   std::lock_guard<std::mutex> lk(*mu);
   if (p->inv_state != 0) return GRAPHOP_OK;
+  {
+    const int rc_cap = check_not_capturing(st, "building the inverse edge permutation of a plan");
+    if (rc_cap != GRAPHOP_OK) return rc_cap;
+  }
   const i64 E = p->info.n_edges;
   p->inv_state = -1;
   if (!p->eid32 || E <= 0 || E >= 0x7fffffffLL) return GRAPHOP_OK;
   DevBuf bad;
-  GO_HIP(hipMalloc(&bad.p, sizeof(int)));
+  GO_HIP(go_malloc(&bad.p, sizeof(int), st));
   GO_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
-  GO_HIP(hipMalloc((void**)&p->inv32, sizeof(int32_t) * (size_t)E));
+  GO_HIP(go_malloc((void**)&p->inv32, sizeof(int32_t) * (size_t)E, st));
   GO_HIP(hipMemsetAsync(p->inv32, 0xff, sizeof(int32_t) * (size_t)E, st));
   hipLaunchKernelGGL(k_inv_scatter, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st,
                      (const int32_t*)p->eid32, E, p->inv32);
@@ -609,9 +689,9 @@ int plan_get_inverse(graphop_plan* p, hipStream_t st) {
   int h_bad = 1;
   GO_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
   GO_HIP(hipStreamSynchronize(st));
-  if (h_bad) { (void)hipFree(p->inv32); p->inv32 = nullptr; return GRAPHOP_OK; }
-  if (hipMalloc((void**)&p->scalar_scratch, sizeof(float) * (size_t)E) != hipSuccess) {
-    (void)hipFree(p->inv32); p->inv32 = nullptr; p->scalar_scratch = nullptr;
+  if (h_bad) { go_free(p->inv32); p->inv32 = nullptr; return GRAPHOP_OK; }
+  if (go_malloc((void**)&p->scalar_scratch, sizeof(float) * (size_t)E, st) != hipSuccess) {
+    go_free(p->inv32); p->inv32 = nullptr; p->scalar_scratch = nullptr;
     return GRAPHOP_OK;
   }
   p->inv_state = 1;

@@ -313,6 +313,18 @@ def attention_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, in
     return [dQ, dK, dV]
 
 
+def prepare(graph, h=1, d=64, dtype=torch.float32, fused=True):
+    """Build a graph's plans and window structures ahead of the first op call (see graphs.prepare)."""
+    from . import graphs
+    return graphs.prepare(graph, h, d, dtype, fused)
+
+
+def release(graph):
+    """Drop a graph's plans (see graphs.release)."""
+    from . import graphs
+    graphs.release(graph)
+
+
 # ---- torch.ops.graphop.* ---------------------------------------------------------------------------
 _SCHEMAS = {
     "maskedmm_csr_forward": "(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor A, Tensor B) -> Tensor",

@@ -180,22 +180,106 @@ SHARDS_OF = {"papers100m": 8, "rmat25": 8}      # the partition the multi-GPU co
 DEFAULT_D = {"papers100m": 128, "rmat25": 256}  # per BASELINE.json
 
 
+# ---- plans: explicit lifecycle ---------------------------------------------------------------------
+def prepare(g, h=1, d=64, dtype=torch.float32, fused=True):
+    """Build the per-graph plans of both orientations AND every window structure the operators will
+    use for node tensors of (n, h, d) `dtype` values, now.  Afterwards no op call on this graph and
+    these shapes allocates or synchronises: do this before capturing a step into a HIP graph, and
+    whenever the first step's latency matters (the ops otherwise build the same things lazily on
+    first use).  Returns (plan_r, plan_c)."""
+    from . import _lib
+    code = _lib.F32 if dtype == torch.float32 else _lib.F64
+    plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, g.n_dst)
+    plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, g.n_src)
+    plan_r.prepare(code, g.n_dst, h, d, fused)      # the row-major side gathers the column-node table
+    plan_c.prepare(code, g.n_src, h, d, fused)
+    return plan_r, plan_c
+
+
+def release(g):
+    """Drop this graph's plans (their device memory returns to torch's allocator)."""
+    from . import _lib
+    _lib.release_plans(g.row, g.col)
+
+
 # ---- on-disk container (next-row N4: the reference caches its index arrays in `i.pt`,
-# wrapper.py:114-116; here one file holds both chunked CSR orientations) ---------------------------
-_GRAPH_FORMAT = 1
+# wrapper.py:114-116; here one file holds both chunked CSR orientations AND the derived plan state:
+# info records, row-segment table, 32-bit index mirrors, every column-window structure built so far,
+# block-dense cover) -----------------------------------------------------------------------------------
+_GRAPH_FORMAT = 2
+_INDEX_FIELDS = ("row", "ptr_r", "eid_r", "indices_r", "col", "ptr_c", "eid_c", "indices_c")
 
 
-def save_graph(g, path):
-    """Write an AttnGraph (all index tensors, on CPU) with torch.save."""
-    payload = {"format": _GRAPH_FORMAT}
+def save_graph(g, path, with_plans=True):
+    """Write an AttnGraph (all index tensors, on CPU) with torch.save.  with_plans: if the graph is
+    on a GPU and has plans (graphs.prepare or any op call), their exported state is stored too, so
+    load_graph(..., device=gpu) re-creates them without analysing the graph again."""
+    payload = {"format": _GRAPH_FORMAT, "plans": None}
     for k, v in g.__dict__.items():
         payload[k] = v.cpu() if isinstance(v, torch.Tensor) else v
+    if with_plans and g.row.is_cuda:
+        from . import _lib
+        plans = {}
+        for side, (row, ptr_, eid, idx) in (("r", (g.row, g.ptr_r, g.eid_r, g.indices_r)),
+                                            ("c", (g.col, g.ptr_c, g.eid_c, g.indices_c))):
+            for ip, ei, ix, _ver, p in row.__dict__.get("_graphop_plans", []):
+                if ip is ptr_ and ei is eid and ix is idx:
+                    plans[side] = p.export_state()
+        payload["plans"] = plans or None
     torch.save(payload, path)
 
 
 def load_graph(path, device="cpu"):
+    """Read a container.  On a GPU device the stored plan state (if any) is imported: the first op
+    call then neither validates the graph nor builds index mirrors or window structures."""
     payload = torch.load(path, map_location="cpu")
-    if payload.pop("format", None) != _GRAPH_FORMAT:
-        raise RuntimeError("load_graph: %s is not a graph container of format %d" % (path, _GRAPH_FORMAT))
+    fmt = payload.pop("format", None)
+    if fmt not in (1, _GRAPH_FORMAT):
+        raise RuntimeError("load_graph: %s is not a graph container of format <= %d" % (path, _GRAPH_FORMAT))
+    plans = payload.pop("plans", None)
     g = AttnGraph(**payload)
-    return g.to(device) if str(device) != "cpu" else g
+    if str(device) == "cpu":
+        return g
+    g = g.to(device)
+    if plans:
+        from . import _lib
+        if "r" in plans:
+            _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, g.n_dst, state=plans["r"])
+        if "c" in plans:
+            _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, g.n_src, state=plans["c"])
+    return g
+
+
+# ---- dlpack interchange (the reference's README TODO "Switch backend to dlpack", README.md:5-7):
+# the eight index arrays of a graph as DLPack capsules / from any __dlpack__ producer -----------------
+def to_dlpack(g):
+    """{name: DLPack capsule} of the eight chunked-CSR arrays, in Function.apply order (zero-copy)."""
+    from torch.utils import dlpack
+    return {k: dlpack.to_dlpack(getattr(g, k)) for k in _INDEX_FIELDS}
+
+
+def from_dlpack(arrays, n_src, n_dst=None, chunk_size=32):
+    """AttnGraph over arrays exported by another framework: `arrays` maps the eight names (row, ptr_r,
+    eid_r, indices_r, col, ptr_c, eid_c, indices_c) to DLPack capsules or objects with __dlpack__
+    (zero-copy; int64 as in the reference API).  indptr / src / dst are re-derived."""
+    n_dst = n_src if n_dst is None else n_dst
+    t = {k: torch.from_dlpack(arrays[k]) for k in _INDEX_FIELDS}
+    for k, v in t.items():
+        if v.dtype != torch.int64:
+            raise RuntimeError("from_dlpack: %s must be int64 (got %s)" % (k, v.dtype))
+    dev = t["row"].device
+    E = int(t["eid_r"].numel())
+
+    def indptr_of(row, ptr, n):
+        # rows' slot ranges from the chunk list (chunks of a row are adjacent, part_csr.py:18-21)
+        ip = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if row.numel():
+            lens = ptr[1:] - ptr[:-1]
+            ip[1:] = torch.cumsum(torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, row, lens), 0)
+        return ip
+
+    indptr_r = indptr_of(t["row"], t["ptr_r"], n_src)
+    indptr_c = indptr_of(t["col"], t["ptr_c"], n_dst)
+    src = torch.repeat_interleave(torch.arange(n_src, device=dev), indptr_r[1:] - indptr_r[:-1])
+    return AttnGraph(n_src, n_dst, E, src, t["indices_r"], indptr_r, indptr_c, t["row"], t["ptr_r"], t["eid_r"],
+                     t["indices_r"], t["col"], t["ptr_c"], t["eid_c"], t["indices_c"], chunk_size)

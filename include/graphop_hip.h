@@ -36,6 +36,7 @@
 #ifndef GRAPHOP_HIP_H_
 #define GRAPHOP_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -75,6 +76,7 @@ typedef struct graphop_plan_info {
   int32_t row_owned;       /* rows_sorted && indptr_monotone: fast paths enabled             */
   int32_t has_idx32;       /* 32-bit mirrors of eid / indices are cached                     */
   int32_t dense_fill_pct;  /* edges per 32x32 tile of the block-dense cover, in %; 0 = no cover */
+  int32_t sorted_in_rows;  /* neighbour ids ascend inside every row segment (window drivers)  */
   int64_t n_dense_blocks;  /* blocks (<= 32 consecutive rows sharing one list of <= 32 ids)   */
 } graphop_plan_info_t;
 
@@ -91,6 +93,20 @@ GRAPHOP_API const char* graphop_last_error(void);
  * attn_window_scale, attn_k, attn_bpc (fused attention kernels).  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
+
+/* ---- device memory of plans ------------------------------------------------------------------
+ * Plans own device arrays (per orientation: 8 B per chunk, 4-8 B per edge of 32-bit mirrors, and
+ * 8 B x windows x rows per window geometry in use; Reddit-shape: ~1.4 GB for both orientations).
+ * By default they come from hipMalloc / hipFree (each a device-wide synchronisation).  A binding
+ * may route them through its framework's allocator: alloc_fn(bytes, device, stream) returns a
+ * device pointer usable on `stream` (NULL = out of memory), free_fn(ptr) releases it with
+ * stream-ordered semantics.  The Python binding registers torch's caching allocator, so plan
+ * memory shows up in (and can be reclaimed by) torch.cuda's accounting.  Pass NULL, NULL to
+ * restore the default; pointers handed out earlier are still freed through the callback that
+ * made them (or left to process exit once it is gone). */
+typedef void* (*graphop_alloc_fn)(size_t bytes, int device, void* stream);
+typedef void (*graphop_free_fn)(void* ptr);
+GRAPHOP_API int graphop_set_allocator(graphop_alloc_fn alloc_fn, graphop_free_fn free_fn);
 
 /* ---- per-kernel timing (measurement aid, off by default) -----------------------------------
  * When enabled, every hot-path kernel launch is bracketed by two hipEvents recorded on the
@@ -131,6 +147,44 @@ GRAPHOP_API int graphop_plan_create(const int64_t* row, const int64_t* indptr, c
                         int64_t n_index_bound, void* stream, graphop_plan_t** plan_out);
 GRAPHOP_API int graphop_plan_info(const graphop_plan_t* plan, graphop_plan_info_t* info_out);
 GRAPHOP_API void graphop_plan_destroy(graphop_plan_t* plan);
+
+/* Build now every cached structure the ops would otherwise build on first use for node tensors of
+ * n_table_rows x (h*d) values gathered through this plan (the column-window structures of the
+ * SDDMM-type, SpMM-type and -- fused != 0 -- fused attention passes).  After it no op call on
+ * these shapes allocates or synchronises: required before capturing the ops into a HIP graph
+ * (an op that would have to build one during capture fails with GRAPHOP_ERR_INVALID_ARGUMENT). */
+GRAPHOP_API int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, int64_t h,
+                         int64_t d, int fused, void* stream);
+
+/* ---- plan persistence (graph container) ---------------------------------------
+ * A plan's derived arrays can be read out and a plan re-created from them WITHOUT analysing the
+ * graph again (graphs.save_graph / load_graph keep them next to the eight index arrays).
+ * graphop_plan_array: device pointer and byte size of one array.  sweep < 0: "seg_chunk" (int64
+ * [n_segments+1]), "idx32", "eid32" (int32 [n_edges]), "long_segs" (int32), "blk_seg", "seg_e0",
+ * "seg_row" (int32; block-dense cover); sweep = i >= 0: "vr_row" (int32 [V]), "wp_lo", "wp_hi"
+ * (int32 [W*V]) of the i-th window structure.  Absent arrays give NULL / 0.
+ * graphop_plan_import trusts its inputs (they come from an export of the same graph); all
+ * pointers are device pointers and are copied. */
+typedef struct graphop_sweep_info {
+  int64_t win_cols; /* neighbour ids per column window */
+  int32_t W;        /* windows */
+  int32_t T;        /* row pieces are at most T slots long */
+  int32_t V;        /* row pieces ("vrows") */
+  int32_t reserved;
+} graphop_sweep_info_t;
+GRAPHOP_API int graphop_plan_n_sweeps(const graphop_plan_t* plan);
+GRAPHOP_API int graphop_plan_sweep_info(const graphop_plan_t* plan, int sweep, graphop_sweep_info_t* out);
+GRAPHOP_API int graphop_plan_array(const graphop_plan_t* plan, const char* name, int sweep, const void** ptr,
+                       int64_t* bytes);
+GRAPHOP_API int graphop_plan_import(const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                        const int64_t* indices, const graphop_plan_info_t* info,
+                        const int64_t* seg_chunk, const int32_t* idx32, const int32_t* eid32,
+                        const int32_t* long_segs, int64_t n_long, const int32_t* blk_seg,
+                        const int32_t* seg_e0, const int32_t* seg_row, void* stream,
+                        graphop_plan_t** plan_out);
+GRAPHOP_API int graphop_plan_import_sweep(graphop_plan_t* plan, const graphop_sweep_info_t* info,
+                              const int32_t* vr_row, const int32_t* wp_lo, const int32_t* wp_hi,
+                              void* stream);
 
 /* ---- SDDMM: maskedmm_csr_forward(row, indptr, eid, indices, A, B) -> y ----------------------
  * replaces graphop.cpp:16-30 / graphop_kernel.cu:269-304 (kernel :40-55).

@@ -117,3 +117,55 @@ def test_block_diagonal_graph_matches_reference_formula():
     indptr_c.append(cnt)
     assert g.eid_c.tolist() == eid_c and g.indices_c.tolist() == indices_c and g.indptr_c.tolist() == indptr_c
     assert g.eid_r.tolist() == list(range(bs * l * l))
+
+
+def test_hot_kernels_do_not_spill():
+    """Register budget of the shipped code object: no window-owner / block-dense / softmax-segment /
+    fused-attention kernel may spill VGPRs or use scratch (each is compiled for a stated number of
+    resident workgroups per CU, kernels_fast.h: sweep_bpc; a spill in their inner loops costs more
+    than the occupancy it buys).  Read from the AMDGPU metadata note of libgraphop_hip.so."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    res = kernel_resources()
+    hot = {n: r for n, r in res.items()
+           if re.search(r"k_(sddmm|spmm)_(wown|sweep|block)_f32|k_softmax_(fwd|bwd)_seg|k_attn_bwd_wown_f32|k_nme_", n)}
+    assert len(hot) > 100, len(hot)
+    bad = {n: r for n, r in hot.items() if r["spill_vgpr"] or r["scratch"]}
+    assert not bad, "\n".join("%s: %r" % kv for kv in sorted(bad.items()))
+    # the headline instantiations keep 4 workgroups per CU (<= 128 VGPRs)
+    for n, r in hot.items():
+        if re.search(r"k_(sddmm|spmm)_wown_f32<16, 1, true", n) or "k_attn_bwd_wown_f32<16, 1, false" in n:
+            assert r["vgpr"] <= 128, (n, r)
+
+
+def test_dlpack_interchange_cpu():
+    """README.md:5-7 TODO of the reference ("Switch backend to dlpack"): the eight index arrays travel
+    as DLPack capsules / from any __dlpack__ producer, zero-copy."""
+    import numpy as np
+    from custom_op_benchmark_amd import graphs
+    g = graphs.uniform_random_graph(40, 500, seed=3, chunk_size=8, n_dst=55)
+    caps = graphs.to_dlpack(g)
+    assert set(caps) == {"row", "ptr_r", "eid_r", "indices_r", "col", "ptr_c", "eid_c", "indices_c"}
+    g2 = graphs.from_dlpack(caps, g.n_src, g.n_dst, chunk_size=8)
+    for k in ("row", "ptr_r", "eid_r", "indices_r", "col", "ptr_c", "eid_c", "indices_c", "indptr_r", "indptr_c", "src", "dst"):
+        assert torch.equal(getattr(g, k), getattr(g2, k)), k
+    assert g2.indices_r.data_ptr() == g.indices_r.data_ptr()        # zero-copy
+    # a foreign producer: numpy arrays implement __dlpack__
+    arrs = {k: np.asarray(getattr(g, k)) for k in caps}
+    g3 = graphs.from_dlpack(arrs, g.n_src, g.n_dst, chunk_size=8)
+    assert torch.equal(g3.indptr_c, g.indptr_c) and torch.equal(g3.eid_c, g.eid_c)
+    with pytest.raises(RuntimeError, match="int64"):
+        bad = dict(arrs); bad["row"] = arrs["row"].astype(np.int32)
+        graphs.from_dlpack(bad, g.n_src, g.n_dst)
+
+
+def test_container_reads_format_1(tmp_path):
+    """Round-1 containers (no plan state) still load."""
+    from custom_op_benchmark_amd import graphs
+    g = graphs.uniform_random_graph(30, 200, seed=5, chunk_size=8)
+    payload = {"format": 1}
+    payload.update({k: v for k, v in g.__dict__.items()})
+    p = str(tmp_path / "old.pt")
+    torch.save(payload, p)
+    assert torch.equal(graphs.load_graph(p).eid_c, g.eid_c)
