@@ -148,11 +148,39 @@ def check(rc):
 
 
 def ptr(t):
-    return _vp(t.data_ptr()) if (t is not None and t.numel() > 0) else _vp(0)
+    # (a plain int / None: ctypes converts it for a c_void_p parameter without building an object)
+    return t.data_ptr() if (t is not None and t.numel() > 0) else None
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_of(t):
-    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    """hipStream_t of torch's current stream on t's device (raw handle, no Stream object)."""
+    idx = t.device.index
+    if _raw_stream is not None and idx is not None:
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class device_guard:
+    """`with torch.cuda.device(d)` without its cost when d already is the current device (the
+    per-op hot path: eight calls per step)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.idx is not None and self.idx != self.prev:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.idx is not None and self.idx != self.prev:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def dtype_code(t):

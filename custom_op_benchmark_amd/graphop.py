@@ -30,7 +30,7 @@ __all__ = ["maskedmm_csr_forward", "maskedmm_csr_backward", "node_mul_edge_forwa
 # extra ops (not in the reference's module): the fused attention step, SURVEY.md 8f N2
 EXTRA_OPS = ["attention_forward", "attention_backward"]
 
-_NULL = _lib._vp(0)
+_NULL = None
 
 
 def _check_input(t, name):
@@ -68,7 +68,7 @@ def maskedmm_csr_forward(row, indptr, eid, indices, A, B):
     e, d = eid.size(0), A.size(-1)
     h = 1 if A.dim() == 2 else A.size(1)                    # graphop_kernel.cu:283
     y = torch.empty((e,) if h == 1 else (e, h), dtype=A.dtype, device=A.device)
-    with torch.cuda.device(A.device):
+    with _lib.device_guard(A.device):
         plan = _plan(row, indptr, eid, indices, B.size(0))
         check(lib().graphop_maskedmm_csr_forward(
             dtype_code(A), ptr(row), ptr(indptr), ptr(eid), ptr(indices), ptr(A), ptr(B), ptr(y),
@@ -93,7 +93,7 @@ def maskedmm_csr_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
     d = A.size(-1)
     h = dy.size(1) if dy.dim() == 2 else 1                  # graphop_kernel.cu:373
     dA, dB = torch.empty_like(A), torch.empty_like(B)
-    with torch.cuda.device(A.device):
+    with _lib.device_guard(A.device):
         plan_r = _plan(row, indptr_r, eid_r, indices_r, B.size(0))
         plan_c = _plan(col, indptr_c, eid_c, indices_c, A.size(0))
         check(lib().graphop_maskedmm_csr_backward(
@@ -112,7 +112,7 @@ def sparse_softmax_forward(row, indptr, eid, x):
         _check_index(t, n)
     h = x.size(1) if x.dim() == 2 else 1
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         plan = _plan(row, indptr, eid, None, 0)
         ws, ws_rows = None, 0
         if not plan.info.row_owned:                          # general layout: atomics + scratch
@@ -136,7 +136,7 @@ def sparse_softmax_backward(row, indptr, eid, y, dy):
     dy = dy.contiguous()
     h = dy.size(1) if dy.dim() == 2 else 1
     dx = torch.empty_like(dy)
-    with torch.cuda.device(y.device):
+    with _lib.device_guard(y.device):
         plan = _plan(row, indptr, eid, None, 0)
         ws, ws_rows = None, 0
         if not plan.info.row_owned:
@@ -159,7 +159,7 @@ def vector_spmm_forward(row, indptr, eid, indices, edata, x):
     h = edata.size(1) if edata.dim() == 2 else 1            # graphop_kernel.cu:520
     d = x.size(-1)
     y = torch.empty_like(x)                                  # zeros_like(x), :527
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         plan = _plan(row, indptr, eid, indices, x.size(0))
         if plan.info.max_row >= x.size(0):
             raise RuntimeError("vector_spmm_forward: row id %d but y = zeros_like(x) has %d rows"
@@ -184,7 +184,7 @@ def vector_spmm_backward(row, indptr, eid, indices, col, indptr_t, eid_t, indice
     h = edata.size(1) if edata.dim() == 2 else 1            # graphop_kernel.cu:560
     d = x.size(-1)
     dedata, dx = torch.empty_like(edata), torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         plan_r = _plan(row, indptr, eid, indices, x.size(0))
         plan_c = _plan(col, indptr_t, eid_t, indices_t, dy.size(0))
         if plan_c.info.max_row >= x.size(0):
@@ -210,7 +210,7 @@ def node_mul_edge_forward(row, indptr, eid, A, B):
     if B.size(0) < e or B.size(-1) != d:
         raise RuntimeError("node_mul_edge_forward: B must be (n_edges, d)")
     y = torch.empty((e,) if h == 1 else (e, h), dtype=A.dtype, device=A.device)
-    with torch.cuda.device(A.device):
+    with _lib.device_guard(A.device):
         plan = _plan(row, indptr, eid, None, 0)
         check(lib().graphop_node_mul_edge_forward(
             dtype_code(A), ptr(row), ptr(indptr), ptr(eid), ptr(A), ptr(B), ptr(y), row.size(0), e,
@@ -235,7 +235,7 @@ def node_mul_edge_backward(row, indptr, eid, A, B, dy):
     if B.size(0) != e or B.size(-1) != d:
         raise RuntimeError("node_mul_edge_backward: B must be (n_edges, d)")
     dA, dB = torch.empty_like(A), torch.empty_like(B)
-    with torch.cuda.device(A.device):
+    with _lib.device_guard(A.device):
         plan = _plan(row, indptr, eid, None, 0)
         check(lib().graphop_node_mul_edge_backward(
             dtype_code(A), ptr(row), ptr(indptr), ptr(eid), ptr(A), ptr(B), ptr(dy), ptr(dA),
@@ -271,7 +271,7 @@ def attention_forward(row, indptr, eid, indices, Q, K, V):
     n_q, n_k = Q.size(0), K.size(0)
     o = torch.empty_like(Q)
     stats = torch.empty((n_q, h, 2), dtype=Q.dtype, device=Q.device)
-    with torch.cuda.device(Q.device):
+    with _lib.device_guard(Q.device):
         plan = _plan(row, indptr, eid, indices, n_k)
         ws, nbytes = _workspace(Q, dtype_code(Q), False, e, n_q, n_k, h, d, plan, None)
         check(lib().graphop_attention_forward(
@@ -301,7 +301,7 @@ def attention_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, in
     if o.shape != Q.shape or dO.shape != Q.shape or stats.numel() != n_q * h * 2:
         raise RuntimeError("attention_backward: o, dO must match Q and stats must be (n_q, h, 2)")
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-    with torch.cuda.device(Q.device):
+    with _lib.device_guard(Q.device):
         plan_r = _plan(row, indptr_r, eid_r, indices_r, n_k)
         plan_c = _plan(col, indptr_c, eid_c, indices_c, n_q)
         ws, nbytes = _workspace(Q, dtype_code(Q), True, e, n_q, n_k, h, d, plan_r, plan_c)

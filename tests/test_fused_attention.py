@@ -100,7 +100,7 @@ def test_fused_window_passes_vs_oracle(dev, force_sweep, d, scale, k, bpc):
 def test_fused_matches_unfused_medium_powerlaw(dev):
     """~1M edges, power-law degrees, d = 64, windows of 64 KB so the fused passes run at a realistic
     tile count; compared with the oracle AND with this library's own unfused composition."""
-    _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 64); _lib.clear_plan_cache()
+    _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 64); _lib.tune("sweep_min_granule", 0); _lib.clear_plan_cache()
     try:
         g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=0)
         inp = rand_inputs(g, 1, 64, seed=7, normal=True)
@@ -117,7 +117,7 @@ def test_fused_matches_unfused_medium_powerlaw(dev):
         for key, ref in (("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
             torch.testing.assert_close(got[key], ref, rtol=2e-4, atol=2e-5)
     finally:
-        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.clear_plan_cache()
+        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
 
 
 def test_fused_uniform_inputs_and_large_scores(dev, force_sweep):

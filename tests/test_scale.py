@@ -1,0 +1,95 @@
+"""GPU tier, BASELINE.json's full sizes and the default kernel geometry.
+
+* products-shape (config 3: N = 2,449,029, E = 61,859,140, 8 heads x d = 128, F = 1024): 10 GB node
+  tensors, 64-bit table offsets (OFF32 = false), the 1024-float row kernels -- too big for the
+  oracle, so size-independent properties (as in test_hip_parity.test_reddit_scale_properties).
+* a 2.5e7-edge power-law graph at the DEFAULT knobs (4 MB windows, automatic piece length, the
+  resident grid the bench uses) against the stock-PyTorch CPU path (oracle/torch_path.py), unfused
+  and fused."""
+import pytest
+import torch
+
+from custom_op_benchmark_amd import _lib, functions, graphs
+from custom_op_benchmark_amd import graphop as ops
+from oracle import torch_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_default_geometry_medium_graph_vs_cpu_path(dev):
+    N, E, d = 60000, 25_000_000, 64
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=3, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    Q, K, V, dO = (torch.randn(N, d, device=dev, generator=gen) / 8 for _ in range(4))
+    q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    _lib.profile_enable(True)
+    s, a, o = functions.attention_step(g, q, k, v, dO)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    # the headline drivers ran, at the default geometry
+    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_wown_f32", prof
+    o0, dQ0, dK0, dV0 = torch_path.attention_step_blocked(g.src.cpu(), g.dst.cpu(), g.indptr_r.cpu(), Q.cpu(), K.cpu(),
+                                                          V.cpu(), dO.cpu(), N, rows_per_block=2048)
+    tol = dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(o.detach().cpu(), o0, **tol)
+    torch.testing.assert_close(q.grad.cpu(), dQ0, **tol)
+    torch.testing.assert_close(k.grad.cpu(), dK0, **tol)
+    torch.testing.assert_close(v.grad.cpu(), dV0, **tol)
+    # the fused op on the same inputs, fused window passes at their default geometry
+    q2, k2, v2 = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    _lib.profile_enable(True)
+    o2 = functions.fused_attention_step(g, q2, k2, v2, dO)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert {"attn_bwd_row", "attn_bwd_col"} <= set(prof), set(prof)
+    torch.testing.assert_close(o2.detach().cpu(), o0, **tol)
+    torch.testing.assert_close(q2.grad.cpu(), dQ0, **tol)
+    torch.testing.assert_close(k2.grad.cpu(), dK0, **tol)
+    torch.testing.assert_close(v2.grad.cpu(), dV0, **tol)
+
+
+def test_products_scale_properties(dev):
+    """BASELINE config 3 (h = 8, d = 128): ones -> d per head and degree; linearity; adjointness ties
+    the forward and both backward passes of every gather op together; rows of the softmax sum to 1."""
+    N, E = graphs.SHAPES["products"]
+    h, d = 8, 128
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 120 << 30:
+        pytest.skip("needs ~110 GB of free HBM")
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev)
+    a4, a8 = (g.row, g.ptr_r, g.eid_r, g.indices_r), g.csr_args()
+    ones = torch.ones(N, h, d, device=dev)
+    s1 = ops.maskedmm_csr_forward(*a4, ones, ones)
+    assert s1.shape == (E, h) and torch.equal(s1, torch.full_like(s1, float(d)))
+    deg = (g.indptr_r[1:] - g.indptr_r[:-1]).float()
+    o1 = ops.vector_spmm_forward(*a4, torch.ones(E, h, device=dev), ones)
+    torch.testing.assert_close(o1[:, 3, 17], deg, rtol=1e-5, atol=0)
+    del s1, o1, ones
+    gen = torch.Generator(device=dev).manual_seed(1)
+    Q = torch.rand(N, h, d, device=dev, generator=gen); K = torch.rand(N, h, d, device=dev, generator=gen)
+    s = ops.maskedmm_csr_forward(*a4, Q, K)
+    assert torch.equal(s, ops.maskedmm_csr_forward(*a4, Q, K))                      # deterministic
+    s2 = ops.maskedmm_csr_forward(*a4, Q * 2, K)
+    torch.testing.assert_close(s2, 2 * s, rtol=1e-6, atol=0)                         # linear in A
+    del s2
+    a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+    rowsum = torch.zeros(N, h, device=dev, dtype=torch.float64).index_add_(0, g.src, a.double())
+    nz = deg > 0
+    torch.testing.assert_close(rowsum[nz], torch.ones_like(rowsum[nz]), rtol=0, atol=1e-5)
+    del rowsum
+    V = torch.rand(N, h, d, device=dev, generator=gen); G = torch.rand(N, h, d, device=dev, generator=gen)
+    o = ops.vector_spmm_forward(*a4, a, V)
+    da, dV = ops.vector_spmm_backward(*a8, a, G, V)
+    lhs = (o.double() * G.double()).sum()
+    torch.testing.assert_close((a.double() * da.double()).sum(), lhs, rtol=1e-6, atol=0)
+    torch.testing.assert_close((V.double() * dV.double()).sum(), lhs, rtol=1e-6, atol=0)
+    del o, dV, V, G
+    dQ, dK = ops.maskedmm_csr_backward(*a8, Q, K, da)
+    ref = (s.double() * da.double()).sum()                     # <SDDMM(Q,K), da> = <Q, dQ> = <K, dK>
+    torch.testing.assert_close((Q.double() * dQ.double()).sum(), ref, rtol=1e-6, atol=0)
+    torch.testing.assert_close((K.double() * dK.double()).sum(), ref, rtol=1e-6, atol=0)
+    dsm = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, torch.full_like(a, 3.0))
+    assert float(dsm.abs().max()) < 1e-4
+    ops.release(g)
