@@ -230,11 +230,16 @@ __device__ __forceinline__ float group_dots_to_owner(float (&p)[SB], int l) {
     const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
     return keep + dpp_f32<0xB1>(send);          // quad_perm [1,0,3,2] = lane ^ 1
   } else if constexpr (L == 16 && SB == 8) {   // lanes u and u + 8 both end up with slot u's sum
-    float t4[4], t2[2];
+    // Same summation tree as the 16-slot form (pairs {l, l^8} first, then ^7, ^2, ^1), so a dot
+    // product recomputed by an 8-slot strip is BITWISE the value a 16-slot strip stored: the fused
+    // attention backward re-derives exp(s - m) from the forward's row maxima.
+    float t8[8], t4[4], t2[2];
     const bool b2 = l & 4, b1 = l & 2, b0 = l & 1;
 #pragma unroll
+    for (int u = 0; u < 8; ++u) t8[u] = p[u] + dpp_f32<0x128>(p[u]);
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float keep = b2 ? p[u + 4] : p[u], send = b2 ? p[u] : p[u + 4];
+      const float keep = b2 ? t8[u + 4] : t8[u], send = b2 ? t8[u] : t8[u + 4];
       t4[u] = keep + dpp_f32<0x141>(send);
     }
 #pragma unroll
@@ -243,8 +248,7 @@ __device__ __forceinline__ float group_dots_to_owner(float (&p)[SB], int l) {
       t2[u] = keep + dpp_f32<0x4E>(send);
     }
     const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
-    const float r = keep + dpp_f32<0xB1>(send);
-    return r + dpp_f32<0x128>(r);
+    return keep + dpp_f32<0xB1>(send);
   } else {
     float res = 0.f;
 #pragma unroll

@@ -124,13 +124,19 @@ def test_fused_uniform_inputs_and_large_scores(dev, force_sweep):
     """U[0,1) features (scores ~ d/4, the harness' input distribution, wrapper.py:151-153) and
     scores of magnitude 1e3: exp(s - m) must not overflow and stats must reproduce a."""
     g = random_graph(800, 800, 12000, seed=31, chunk_size=32, hub=700)
-    for scale in (1.0, 30.0):
+    # |s| ~ 16 and ~ 260: fp32 tolerance.  |s| ~ 1.4e4: one ulp of s is 1e-3, and a = exp(s - m)
+    # carries that as a RELATIVE error whatever the implementation (the oracle's serial sums included),
+    # so only a loose bound is meaningful there; what must hold is that nothing overflows (a <= 1:
+    # the backward recomputes s bitwise as the forward stored it) and no NaN / inf appears.
+    for scale, tol in ((1.0, dict(rtol=2e-4, atol=2e-5)), (4.0, dict(rtol=2e-4, atol=1e-4)),
+                       (30.0, dict(rtol=2e-2, atol=1e-2))):
         inp = rand_inputs(g, 1, 64, seed=12)
         Q, K = inp["Q"] * scale, inp["K"] * scale
         want = oracle_step(oracle, g, Q, K, inp["V"], inp["dO"])
         got = fused_step(g.to(dev), Q.to(dev), K.to(dev), inp["V"].to(dev), inp["dO"].to(dev))
         for key in ("o", "dQ", "dK", "dV"):
-            close(got[key], want[key], rtol=2e-4, atol=2e-5)
+            assert torch.isfinite(got[key]).all(), key
+            close(got[key], want[key], **tol)
 
 
 def test_fused_forward_stats(dev):

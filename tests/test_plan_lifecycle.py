@@ -112,7 +112,7 @@ def test_container_carries_plan_state(dev, tmp_path, small_windows):
     """save_graph on a prepared GPU graph stores info records, segment tables, 32-bit mirrors and the
     window structures; load_graph(device=gpu) imports them: the first step builds nothing and matches
     the oracle."""
-    g = random_graph(1500, 1541, 15000, seed=9, chunk_size=32, zero_rows=0.1, hub=900)
+    g = random_graph(1500, 1500, 15000, seed=9, chunk_size=32, zero_rows=0.1, hub=900)
     inp = rand_inputs(g, 1, 64, seed=8, normal=True)
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"][:g.n_src])
     gd = g.to(dev)

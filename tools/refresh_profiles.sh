@@ -1,15 +1,17 @@
 #!/bin/bash
 # Re-create the measurements kept under profiles/ (run on the GPU box from the repo root):
-#   bash tools/refresh_profiles.sh <tag>      e.g. r1_final  -> gpurun_out/<tag>_*
-# bench line, rocprofv3 kernel stats of the same command, separate --pmc passes, and the bench
-# lines of the other shapes.  Copy the files you want judged into profiles/.
+#   bash tools/refresh_profiles.sh <tag> [quick]     e.g. r2_final  -> gpurun_out/<tag>_*
+# bench line, rocprofv3 kernel stats of the same command, separate --pmc passes (one counter group
+# per pass: more than that exceeds the hardware's counter slots and rocprofv3 aborts), and the
+# bench lines of the other workloads / input variants.  Copy the files you want judged into profiles/.
 set -eo pipefail
-TAG=${1:-r1_final}
+TAG=${1:-r2_final}
+QUICK=${2:-}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-python bench.py --steps 10 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "[refresh] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o stats -- \
     python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 \
@@ -27,10 +29,20 @@ echo "[refresh] pmc l2 done"
 python tools/pmc_summary.py "$(dirname "$(find "$OUT/pmc_$TAG" -name 'l2_counter_collection.csv' | head -1)")" \
     FETCH_SIZE WRITE_SIZE l2 > "$OUT/${TAG}_pmc_summary.json"
 python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 > "$OUT/${TAG}_pmc_traffic.json"
+[ -n "$QUICK" ] && { echo "[refresh] quick: done"; exit 0; }
+# input variants of the headline workload: worst-case locality, signed values
+python bench.py --alpha 0 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_alpha0_bench.json" 2>/dev/null
+python bench.py --values normal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_normal_bench.json" 2>/dev/null
+echo "[refresh] variants done"
 python bench.py --graph harness --d 1024 --heads 1 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_d1024_bench.json" 2>/dev/null
 python bench.py --graph harness --d 64 --heads 8 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_8x64_bench.json" 2>/dev/null
-python bench.py --graph cora --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_cora_bench.json" 2>/dev/null
+python bench.py --graph cora --steps 50 --warmup 5 > "$OUT/${TAG}_cora_bench.json" 2>/dev/null
+python bench.py --graph cora --steps 50 --warmup 5 --no-cpu-baseline --hip-graph > "$OUT/${TAG}_cora_hipgraph_bench.json" 2>/dev/null
 echo "[refresh] small shapes done"
 python bench.py --graph products --d 16 --heads 8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d16_bench.json" 2>/dev/null
-python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
+python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --cpu-sample-edges 1500000 > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
+echo "[refresh] products done"
+# one-GPU rehearsal of rank 0's shard of the 8-way multi-GPU configs (timing only: exchanges = local copies)
+python bench.py --emulate-world 8 --graph papers100m --steps 5 --warmup 2 > "$OUT/${TAG}_emulate8_papers100m_bench.json" 2>/dev/null
+python bench.py --emulate-world 8 --graph rmat25 --steps 3 --warmup 1 > "$OUT/${TAG}_emulate8_rmat25_bench.json" 2>/dev/null
 echo "[refresh] all done"
