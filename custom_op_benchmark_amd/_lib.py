@@ -75,6 +75,7 @@ _SIGNATURES = {
     "graphop_scatter_add_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_attention_workspace_bytes": [ctypes.c_int, ctypes.c_int] + [_c64] * 5 + [_P, _P, _P,
                                                                                        ctypes.POINTER(_c64)],
+    "graphop_attention_backward_is_fused": [ctypes.c_int] + [_c64] * 5 + [_P, _P, _P, ctypes.POINTER(ctypes.c_int)],
     "graphop_attention_forward": [ctypes.c_int] + [_P] * 9 + [_c64] * 6 + [_P, _c64, _P, _P],
     "graphop_attention_backward": [ctypes.c_int] + [_P] * 17 + [_c64] * 7 + [_P, _c64, _P, _P, _P],
 }

@@ -148,6 +148,18 @@ int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, 
   return GRAPHOP_OK;
 }
 
+int graphop_attention_backward_is_fused(int dtype, int64_t n_edges, int64_t n_q, int64_t n_k, int64_t h,
+                                        int64_t d, const graphop_plan_t* plan_r,
+                                        const graphop_plan_t* plan_c, void* stream, int* fused_out) {
+  GO_CHECK_ARG(fused_out != nullptr, "attention_backward_is_fused: fused_out is NULL");
+  AttnFast af;
+  const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
+                                  /*dry_run=*/true, &af);
+  if (fast < 0) return -fast;
+  *fused_out = fast;
+  return GRAPHOP_OK;
+}
+
 int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
                               const int64_t* indices, const void* Q, const void* K, const void* V,
                               void* o, void* stats, int64_t n_chunks, int64_t n_edges, int64_t n_q,

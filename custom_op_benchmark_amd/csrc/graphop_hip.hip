@@ -527,14 +527,15 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
-      if (h == 1)
-        hipLaunchKernelGGL((k_spmm_f32<L, NV, true>), dim3(nb), dim3(kFastBlock), 0, st, row,
-                           indptr, eid, indices, (const float*)w, (const float*)X, (float*)out, C,
-                           (int)h, d4, cpg);
-      else
-        hipLaunchKernelGGL((k_spmm_f32<L, NV, false>), dim3(nb), dim3(kFastBlock), 0, st, row,
-                           indptr, eid, indices, (const float*)w, (const float*)X, (float*)out, C,
-                           (int)h, d4, cpg);
+      // plan.rows_sorted: a row's chunks are adjacent, rows inside one group's range need no atomics
+      const bool owned = plan && plan->info.rows_sorted && ((uintptr_t)out & 15) == 0;
+      auto go = [&](auto h1, auto ow) {
+        hipLaunchKernelGGL((k_spmm_f32<L, NV, decltype(h1)::value, decltype(ow)::value>), dim3(nb),
+                           dim3(kFastBlock), 0, st, row, indptr, eid, indices, (const float*)w,
+                           (const float*)X, (float*)out, C, (int)h, d4, cpg);
+      };
+      if (h == 1) { if (owned) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
+      else { if (owned) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }
     });
   } else {
     ProfScope prof(tag, st, "k_spmm_generic");

@@ -83,17 +83,36 @@ class FusedAttention(Function):
 
     @staticmethod
     def forward(ctx, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V):
-        o, stats = _ops.attention_forward(row, indptr_r, eid_r, indices_r, Q, K, V)
-        ctx.save_for_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V,
-                              o, stats)
+        a8 = (row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c)
+        ctx.fused = _ops.attention_backward_is_fused(*a8, Q, K)
+        if ctx.fused:
+            o, stats = _ops.attention_forward(row, indptr_r, eid_r, indices_r, Q, K, V)
+            ctx.save_for_backward(*a8, Q, K, V, o, stats)
+        else:
+            # the fused passes do not apply (several heads, fp64, short rows ...): keep a for the unfused
+            # backward ops instead of letting attention_backward recompute s and a
+            s = _ops.maskedmm_csr_forward(row, indptr_r, eid_r, indices_r, Q, K)
+            a = _ops.sparse_softmax_forward(row, indptr_r, eid_r, s)
+            del s
+            o = _ops.vector_spmm_forward(row, indptr_r, eid_r, indices_r, a, V)
+            if o.size(0) != Q.size(0):
+                o = o[:Q.size(0)]
+            ctx.save_for_backward(*a8, Q, K, V, a)
         return o
 
     @staticmethod
     def backward(ctx, dO):
-        (row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V, o,
-         stats) = ctx.saved_tensors
-        dQ, dK, dV = _ops.attention_backward(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c,
-                                             indices_c, Q, K, V, o, stats, dO)
+        a8, rest = ctx.saved_tensors[:8], ctx.saved_tensors[8:]
+        row, indptr_r, eid_r = a8[:3]
+        if ctx.fused:
+            Q, K, V, o, stats = rest
+            dQ, dK, dV = _ops.attention_backward(*a8, Q, K, V, o, stats, dO)
+        else:
+            Q, K, V, a = rest
+            da, dV = _ops.vector_spmm_backward(*a8, a, dO.contiguous(), V)
+            ds = _ops.sparse_softmax_backward(row, indptr_r, eid_r, a, da)
+            del da
+            dQ, dK = _ops.maskedmm_csr_backward(*a8, Q, K, ds)
         return None, None, None, None, None, None, None, None, dQ, dK, dV
 
 

@@ -28,7 +28,7 @@ __all__ = ["maskedmm_csr_forward", "maskedmm_csr_backward", "node_mul_edge_forwa
            "node_mul_edge_backward", "sparse_softmax_forward", "sparse_softmax_backward",
            "vector_spmm_forward", "vector_spmm_backward"]
 # extra ops (not in the reference's module): the fused attention step, SURVEY.md 8f N2
-EXTRA_OPS = ["attention_forward", "attention_backward"]
+EXTRA_OPS = ["attention_forward", "attention_backward", "attention_backward_is_fused"]
 
 _NULL = None
 
@@ -251,6 +251,22 @@ def _workspace(like, dtype, backward, e, n_q, n_k, h, d, plan_r, plan_c):
         dtype, 1 if backward else 0, e, n_q, n_k, h, d, plan_r.handle if plan_r is not None else _NULL,
         plan_c.handle if plan_c is not None else _NULL, stream_of(like), ctypes.byref(nbytes)))
     return torch.empty(max(1, nbytes.value), dtype=torch.uint8, device=like.device), nbytes.value
+
+
+def attention_backward_is_fused(row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K):
+    """True when attention_backward will run its fused window passes for this graph and these
+    shapes (fp32, one head, sweepable plans, tables beyond the L2); False when it would compose
+    the unfused ops, recomputing s and a."""
+    import ctypes
+    d = Q.size(-1)
+    h = 1 if Q.dim() == 2 else Q.size(1)
+    out = ctypes.c_int(0)
+    with _lib.device_guard(Q.device):
+        plan_r = _plan(row, indptr_r, eid_r, indices_r, K.size(0))
+        plan_c = _plan(col, indptr_c, eid_c, indices_c, Q.size(0))
+        check(lib().graphop_attention_backward_is_fused(dtype_code(Q), eid_r.size(0), Q.size(0), K.size(0), h, d,
+                                                        plan_r.handle, plan_c.handle, stream_of(Q), ctypes.byref(out)))
+    return bool(out.value)
 
 
 def attention_forward(row, indptr, eid, indices, Q, K, V):

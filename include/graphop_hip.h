@@ -291,6 +291,12 @@ GRAPHOP_API int graphop_attention_workspace_bytes(int dtype, int backward, int64
                                       int64_t n_k, int64_t h, int64_t d,
                                       const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
                                       void* stream, int64_t* bytes_out);
+/* 1 when graphop_attention_backward will run its fused window passes for these shapes / plans, 0 when
+ * it will compose the unfused entry points (and recompute s and a first): a caller that can keep a
+ * from its forward (the Python autograd class does) then prefers the unfused backward ops. */
+GRAPHOP_API int graphop_attention_backward_is_fused(int dtype, int64_t n_edges, int64_t n_q, int64_t n_k, int64_t h,
+                                        int64_t d, const graphop_plan_t* plan_r,
+                                        const graphop_plan_t* plan_c, void* stream, int* fused_out);
 GRAPHOP_API int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
                               const int64_t* indices, const void* Q, const void* K, const void* V,
                               void* o, void* stats, int64_t n_chunks, int64_t n_edges, int64_t n_q,
