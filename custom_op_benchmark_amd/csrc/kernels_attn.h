@@ -236,8 +236,13 @@ __global__ __launch_bounds__(kFastBlock, BPC) void k_attn_bwd_wown_f32(
     const int row_l = cur.row;
     auto to_out = [&](int k, const float4 (&acc0)[NV], const float4 (&acc1)[COL ? NV : 1]) {
       const i64 r = __shfl(row_l, k, L);
+#ifdef GRAPHOP_DEBUG_NOFLUSH   // measurement builds only (wrong results): what the partial-row flushes cost
+      if (acc0[0].x == 1234.5f) atomic_flush_dense<L, NV>(out0, r, acc0, l);
+      if constexpr (COL) { if (acc1[0].x == 1234.5f) atomic_flush_dense<L, NV>(out1, r, acc1, l); }
+#else
       atomic_flush_dense<L, NV>(out0, r, acc0, l);
       if constexpr (COL) atomic_flush_dense<L, NV>(out1, r, acc1, l);
+#endif
     };
     attn_bwd_strip<L, NV, COL, OFF32>(to_out, stage_rows, mine, cur.lo, cur.hi - cur.lo, s.idx32, XT,
                                       stats4, own_st, l);

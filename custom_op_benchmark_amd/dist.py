@@ -12,9 +12,14 @@ asks for it.  Design:
   n_own x (n_own + n_halo) chunked CSR and runs through the unchanged single-GPU operators.
 * Forward exchange: a variable-size all_to_all delivers the halo rows of K (and one more those of
   V) straight into the tail of preallocated extended tensors -- no packing, no concatenation.
-  Both are started together (async); the V rows are awaited only in front of the SpMM, and the
-  returning dV rows travel under the softmax / SDDMM backward: two of the four exchanges overlap
-  with compute.
+  Both are started together (async); the V rows are awaited only in front of the SpMM, the
+  returning dV rows travel under the softmax / SDDMM backward, and the returning dK rows under the
+  row-major half of the SDDMM backward (the op is called once per orientation): three of the four
+  exchanges overlap with compute.  The forward K exchange is exposed: hiding it needs the local
+  graph split into own-column and halo-column halves with outputs accumulated in place, which
+  the reference's operator surface (fresh zero-filled outputs per call) does not offer -- composed
+  from whole-output calls it costs more zero fills and adds than the ~4 % it would hide at the
+  papers100M-shape shard.
   Backward exchange: the partial dK / dV rows computed for halo columns (a contiguous slice of the
   operators' outputs) travel back with the transposed split sizes and are added into the owners' rows.
   xGMI is point-to-point: all_to_all drives all 7 links of a GPU at once; no ring collective.
@@ -142,6 +147,9 @@ class ShardedAttention:
         self.local = group if isinstance(group, _LocalHandle) else None
         self._buffers = {}
         self.timers = None       # set to {} to collect per-exchange wall times (bench.py)
+        # SDDMM backward as two calls (column-major half, then row-major half) so that the dK halo
+        # exchange runs under the dQ pass; costs one extra zero fill of a K_ext-sized tensor
+        self.split_backward = True
         self.device = torch.device(device)
         self.ops = ops
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -327,16 +335,41 @@ class ShardedAttention:
         if exchange:
             wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True, role="dV")
         ds = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
-        dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd, K_ext, ds)
-        dK = dK_ext[:n_own]
-        if exchange:
-            self.scatter_halo_grad(dK, dK_ext[n_own:], role="dK")
+        if exchange and self.split_backward:
+            # column-major half first (dK incl. the halo columns' partial rows), start sending those
+            # home, then the row-major half (dQ) runs under that exchange.  Each half is the same
+            # entry point with the other orientation's chunk list empty.
+            er, ep = self._empty_chunks()
+            _, dK_ext = ops.maskedmm_csr_backward(er, ep, g.eid_r, g.indices_r, g.col, g.ptr_c, g.eid_c,
+                                                  g.indices_c, Qd, K_ext, ds)
+            dK = dK_ext[:n_own]
+            wait_dk, recv_dk = self.scatter_halo_grad_start(dK, dK_ext[n_own:], async_op=True, role="dK")
+            dQ, _ = ops.maskedmm_csr_backward(g.row, g.ptr_r, g.eid_r, g.indices_r, er, ep, g.eid_c,
+                                              g.indices_c, Qd, K_ext, ds)
+            wait_dk.wait()
+            self._add_home(dK, recv_dk)
             wait_dv.wait()
             self._add_home(dV, recv_dv)
+        else:
+            dQ, dK_ext = ops.maskedmm_csr_backward(*a8, Qd, K_ext, ds)
+            dK = dK_ext[:n_own]
+            if exchange:
+                self.scatter_halo_grad(dK, dK_ext[n_own:], role="dK")
+                wait_dv.wait()
+                self._add_home(dV, recv_dv)
         for t, gr in ((Q, dQ), (K, dK), (V, dV)):
             if t.requires_grad:
                 t.grad = gr
         return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    def _empty_chunks(self):
+        """(row[0], indptr[1] = [0]): a chunk list that covers nothing (int64, on this shard's device)."""
+        e = self._buffers.get("empty_chunks")
+        if e is None:
+            e = (torch.zeros(0, dtype=torch.int64, device=self.device),
+                 torch.zeros(1, dtype=torch.int64, device=self.device))
+            self._buffers["empty_chunks"] = e
+        return e
 
     def halo_stats(self, row_bytes):
         """What this rank moves per step: rows / bytes received (K and V forward) and sent back
