@@ -137,6 +137,17 @@ hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
 
 namespace {
 
+// Chunks per lane group of the chunk drivers: the tuned value amortises row switches on big graphs,
+// but a small graph (Cora-shape: 2.8 K chunks) must still put a few lane groups on every CU --
+// 16 chunks per group there left 13 workgroups walking chunks serially (33 us per pass).
+inline int cpg_for(i64 n_chunks, int cpg_max, int F) {
+  const int lanes = F >= 256 ? 64 : (F / 4 > 0 ? F / 4 : 1);
+  const i64 groups_wanted = (i64)tuning().n_cu * (kFastBlock / lanes) * 8;
+  i64 c = n_chunks / (groups_wanted > 0 ? groups_wanted : 1);
+  if (c < 1) c = 1;
+  return (int)(c < cpg_max ? c : cpg_max);
+}
+
 inline unsigned blocks_for(i64 work, i64 per_block) {
   i64 b = ceil_div(work > 0 ? work : 1, per_block);
   return (unsigned)b;
@@ -467,7 +478,7 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
   }
   // EDGE_B (node_mul_edge): B rows are d wide, A rows h*d wide -> fast path only for h == 1
   if (fast_ok(dtype, h, d, E, n_src_rows) && (!EDGE_B || h == 1)) {
-    const int cpg = tuning().sddmm_cpg;
+    const int cpg = cpg_for(C, tuning().sddmm_cpg, (int)(h * d));
     const int F = (int)(h * d), d4 = (int)(d / 4);
     if constexpr (!EDGE_B) {
       int use = 0;
@@ -515,7 +526,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
     if (try_spmm_block(tag, dtype, plan, n_src_rows, w, X, out, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
   }
   if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
-    const int cpg = tuning().spmm_cpg;
+    const int cpg = cpg_for(C, tuning().spmm_cpg, (int)(h * d));
     const int F = (int)(h * d), d4 = (int)(d / 4);
     {
       int use = 0;

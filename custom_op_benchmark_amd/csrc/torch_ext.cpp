@@ -1,0 +1,368 @@
+// graphop_cpp: the reference's operator boundary as a compiled PyTorch-ROCm C++ extension.
+//
+// Same shape as the reference's graphop/graphop.cpp (:1-225): CHECK_CUDA / CHECK_CONTIGUOUS on every
+// input (:4-6), eight functions on at::Tensor with the reference's positional signatures and return
+// types (:16-30, :39-51, :59-69, :79-93, :108-131, :141-154, :163-175, :190-214), exported twice:
+//   * PYBIND11_MODULE  -> importable module (the reference's only registration, :216-225)
+//   * TORCH_LIBRARY(graphop, ...) -> torch.ops.graphop.* (north_star's surface; the reference has none)
+// Where the reference forwards to its *_cuda_* launchers, this file forwards to the C ABI of
+// libgraphop_hip.so (include/graphop_hip.h) on the current HIP stream.  It owns a small per-graph plan
+// cache (graphop_plan_create is the setup path: validation + derived arrays); everything else --
+// kernels, dispatch, workspaces' layout -- lives behind the C ABI.  The ctypes binding
+// (custom_op_benchmark_amd/graphop.py) is the same boundary without a compiler.
+#include <torch/extension.h>
+#include <torch/library.h>
+#include <c10/hip/HIPStream.h>
+
+#include <list>
+#include <mutex>
+#include <tuple>
+#include <unordered_map>
+
+#include "graphop_hip.h"
+
+#define CHECK_CUDA(x) TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor")            // graphop.cpp:4
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")   // graphop.cpp:5
+#define CHECK_INPUT(x) CHECK_CUDA(x); CHECK_CONTIGUOUS(x)                                // graphop.cpp:6
+#define CHECK_INDEX(x) TORCH_CHECK((x).scalar_type() == at::kLong, "expected scalar type Long but found ", (x).scalar_type(), " (" #x ")")
+
+namespace {
+
+void check(int rc) { TORCH_CHECK(rc == GRAPHOP_OK, "graphop: ", graphop_last_error()); }
+
+int dtype_code(const at::Tensor& t) {
+  if (t.scalar_type() == at::kFloat) return GRAPHOP_F32;
+  if (t.scalar_type() == at::kDouble) return GRAPHOP_F64;
+  TORCH_CHECK(false, "graphop: not implemented for '", t.scalar_type(), "' (float32 / float64 only)");   // AT_DISPATCH_FLOATING_TYPES, graphop_kernel.cu:291
+}
+
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+const int64_t* ip(const at::Tensor& t) { return t.numel() ? t.data_ptr<int64_t>() : nullptr; }
+void* vp(const at::Tensor& t) { return t.numel() ? t.data_ptr() : nullptr; }
+
+// ---- plans: least-recently-used cache keyed by the identity and version of the four index tensors ----
+struct PlanKey {
+  const void *row, *indptr, *eid, *indices;
+  int64_t n_chunks, n_edges;
+  uint32_t v0, v1, v2, v3;
+  int device;
+  bool operator==(const PlanKey& o) const {
+    return row == o.row && indptr == o.indptr && eid == o.eid && indices == o.indices && n_chunks == o.n_chunks &&
+           n_edges == o.n_edges && v0 == o.v0 && v1 == o.v1 && v2 == o.v2 && v3 == o.v3 && device == o.device;
+  }
+};
+struct PlanKeyHash {
+  size_t operator()(const PlanKey& k) const {
+    size_t h = std::hash<const void*>()(k.row);
+    for (const void* p : {k.indptr, k.eid, k.indices}) h = h * 1000003u ^ std::hash<const void*>()(p);
+    return h ^ (size_t)k.n_edges ^ ((size_t)k.v0 << 7) ^ ((size_t)k.v3 << 13);
+  }
+};
+struct PlanEntry {
+  graphop_plan_t* plan;
+  graphop_plan_info_t info;
+  std::vector<at::Tensor> keep;   // the arrays the plan points into stay alive with it
+  std::list<PlanKey>::iterator lru;
+};
+std::mutex g_mu;
+std::unordered_map<PlanKey, PlanEntry, PlanKeyHash> g_plans;
+std::list<PlanKey> g_lru;
+constexpr size_t kMaxPlans = 64;
+
+const PlanEntry& get_plan(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                          const at::Tensor& indices, int64_t bound) {
+  PlanKey k{row.numel() ? row.data_ptr() : nullptr, indptr.data_ptr(), eid.numel() ? eid.data_ptr() : nullptr,
+            indices.numel() ? indices.data_ptr() : nullptr, row.numel(), eid.numel(), row._version(),
+            indptr._version(), eid._version(), indices._version(), (int)indptr.get_device()};
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find(k);
+  if (it == g_plans.end()) {
+    while (g_plans.size() >= kMaxPlans) {
+      auto victim = g_plans.find(g_lru.back());
+      graphop_plan_destroy(victim->second.plan);
+      g_plans.erase(victim);
+      g_lru.pop_back();
+    }
+    PlanEntry e;
+    e.plan = nullptr;
+    check(graphop_plan_create(ip(row), ip(indptr), ip(eid), ip(indices), row.numel(), eid.numel(), bound,
+                              stream_of(indptr), &e.plan));
+    check(graphop_plan_info(e.plan, &e.info));
+    e.keep = {row, indptr, eid, indices};
+    g_lru.push_front(k);
+    e.lru = g_lru.begin();
+    it = g_plans.emplace(k, std::move(e)).first;
+  } else {
+    g_lru.splice(g_lru.begin(), g_lru, it->second.lru);
+  }
+  TORCH_CHECK(bound <= 0 || it->second.info.max_index < bound, "graphop: indices holds ", it->second.info.max_index,
+              " but the gathered tensor has only ", bound, " rows");
+  return it->second;
+}
+
+struct DeviceGuard {   // the reference calls cudaSetDevice without restoring (graphop_kernel.cu:277)
+  c10::DeviceGuard g;
+  explicit DeviceGuard(const at::Tensor& t) : g(t.device()) {}
+};
+
+at::Tensor edge_out(const at::Tensor& like, int64_t e, int64_t h) {   // (e) if h == 1 else (e, h), graphop_kernel.cu:284
+  return h == 1 ? at::empty({e}, like.options()) : at::empty({e, h}, like.options());
+}
+
+}  // namespace
+
+// ---- the eight functions (graphop.cpp:16-214) ------------------------------------------------------
+at::Tensor maskedmm_csr_forward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                const at::Tensor& indices, const at::Tensor& A, const at::Tensor& B) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(indices); CHECK_INPUT(A); CHECK_INPUT(B);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid); CHECK_INDEX(indices);
+  TORCH_CHECK(A.scalar_type() == B.scalar_type(), "expected A and B to have the same dtype");
+  DeviceGuard dg(A);
+  const int64_t e = eid.size(0), d = A.size(-1), h = A.dim() == 2 ? 1 : A.size(1);   // graphop_kernel.cu:282-283
+  auto y = edge_out(A, e, h);
+  const auto& p = get_plan(row, indptr, eid, indices, B.size(0));
+  check(graphop_maskedmm_csr_forward(dtype_code(A), ip(row), ip(indptr), ip(eid), ip(indices), vp(A), vp(B), vp(y),
+                                     row.size(0), e, A.size(0), B.size(0), h, d, p.plan, stream_of(A)));
+  return y;
+}
+
+std::vector<at::Tensor> maskedmm_csr_backward(const at::Tensor& row, const at::Tensor& indptr_r,
+                                              const at::Tensor& eid_r, const at::Tensor& indices_r,
+                                              const at::Tensor& col, const at::Tensor& indptr_c,
+                                              const at::Tensor& eid_c, const at::Tensor& indices_c,
+                                              const at::Tensor& A, const at::Tensor& B, const at::Tensor& dy_) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr_r); CHECK_INPUT(eid_r); CHECK_INPUT(indices_r);
+  CHECK_INPUT(col); CHECK_INPUT(indptr_c); CHECK_INPUT(eid_c); CHECK_INPUT(indices_c); CHECK_INPUT(A); CHECK_INPUT(B);
+  CHECK_INDEX(row); CHECK_INDEX(indptr_r); CHECK_INDEX(eid_r); CHECK_INDEX(indices_r);
+  CHECK_INDEX(col); CHECK_INDEX(indptr_c); CHECK_INDEX(eid_c); CHECK_INDEX(indices_c);
+  CHECK_CUDA(dy_);
+  const at::Tensor dy = dy_.contiguous();   // the reference forgets this check (graphop.cpp:120-129)
+  DeviceGuard dg(A);
+  const int64_t d = A.size(-1), h = dy.dim() == 2 ? dy.size(1) : 1;   // graphop_kernel.cu:373
+  auto dA = at::empty_like(A), dB = at::empty_like(B);
+  const auto& pr = get_plan(row, indptr_r, eid_r, indices_r, B.size(0));
+  const auto& pc = get_plan(col, indptr_c, eid_c, indices_c, A.size(0));
+  check(graphop_maskedmm_csr_backward(dtype_code(A), ip(row), ip(indptr_r), ip(eid_r), ip(indices_r), ip(col),
+                                      ip(indptr_c), ip(eid_c), ip(indices_c), vp(A), vp(B), vp(dy), vp(dA), vp(dB),
+                                      row.size(0), col.size(0), eid_r.size(0), A.size(0), B.size(0), h, d, pr.plan,
+                                      pc.plan, stream_of(A)));
+  return {dA, dB};
+}
+
+at::Tensor node_mul_edge_forward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                 const at::Tensor& A, const at::Tensor& B) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(A); CHECK_INPUT(B);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid);
+  DeviceGuard dg(A);
+  const int64_t e = eid.size(0), d = A.size(-1), h = A.dim() == 2 ? 1 : A.size(1);
+  TORCH_CHECK(B.size(0) >= e && B.size(-1) == d, "node_mul_edge_forward: B must be (n_edges, d)");
+  auto y = edge_out(A, e, h);
+  const auto& p = get_plan(row, indptr, eid, at::Tensor(at::empty({0}, eid.options())), 0);
+  check(graphop_node_mul_edge_forward(dtype_code(A), ip(row), ip(indptr), ip(eid), vp(A), vp(B), vp(y), row.size(0), e,
+                                      A.size(0), h, d, p.plan, stream_of(A)));
+  return y;
+}
+
+std::vector<at::Tensor> node_mul_edge_backward(const at::Tensor& row, const at::Tensor& indptr,
+                                               const at::Tensor& eid, const at::Tensor& A, const at::Tensor& B,
+                                               const at::Tensor& dy_) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(A); CHECK_INPUT(B);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid);
+  CHECK_CUDA(dy_);
+  const at::Tensor dy = dy_.contiguous();
+  DeviceGuard dg(A);
+  const int64_t e = eid.size(0), d = A.size(-1), h = dy.dim() == 2 ? dy.size(1) : 1;
+  TORCH_CHECK(B.size(0) == e && B.size(-1) == d, "node_mul_edge_backward: B must be (n_edges, d)");
+  auto dA = at::empty_like(A), dB = at::empty_like(B);
+  const auto& p = get_plan(row, indptr, eid, at::Tensor(at::empty({0}, eid.options())), 0);
+  check(graphop_node_mul_edge_backward(dtype_code(A), ip(row), ip(indptr), ip(eid), vp(A), vp(B), vp(dy), vp(dA),
+                                       vp(dB), row.size(0), e, A.size(0), h, d, p.plan, stream_of(A)));
+  return {dA, dB};
+}
+
+at::Tensor sparse_softmax_forward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                  const at::Tensor& x) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(x);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid);
+  DeviceGuard dg(x);
+  const int64_t h = x.dim() == 2 ? x.size(1) : 1;
+  auto y = at::empty_like(x);
+  const auto& p = get_plan(row, indptr, eid, at::Tensor(at::empty({0}, eid.options())), 0);
+  at::Tensor ws;
+  int64_t ws_rows = 0;
+  if (!p.info.row_owned) {   // general layout: max / sum scratch per row (the reference sizes it by E, :426-427)
+    ws_rows = p.info.max_row + 1;
+    ws = at::empty({2 * ws_rows * h}, x.options());
+  }
+  check(graphop_sparse_softmax_forward(dtype_code(x), ip(row), ip(indptr), ip(eid), vp(x), vp(y), row.size(0),
+                                       eid.size(0), h, ws.defined() ? vp(ws) : nullptr, ws_rows, p.plan, stream_of(x)));
+  return y;
+}
+
+at::Tensor sparse_softmax_backward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                   const at::Tensor& y, const at::Tensor& dy_) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(y);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid);
+  CHECK_CUDA(dy_);
+  const at::Tensor dy = dy_.contiguous();
+  DeviceGuard dg(y);
+  const int64_t h = dy.dim() == 2 ? dy.size(1) : 1;
+  auto dx = at::empty_like(dy);
+  const auto& p = get_plan(row, indptr, eid, at::Tensor(at::empty({0}, eid.options())), 0);
+  at::Tensor ws;
+  int64_t ws_rows = 0;
+  if (!p.info.row_owned) {
+    ws_rows = p.info.max_row + 1;
+    ws = at::empty({ws_rows * h}, y.options());
+  }
+  check(graphop_sparse_softmax_backward(dtype_code(y), ip(row), ip(indptr), ip(eid), vp(y), vp(dy), vp(dx), row.size(0),
+                                        eid.size(0), h, ws.defined() ? vp(ws) : nullptr, ws_rows, p.plan, stream_of(y)));
+  return dx;
+}
+
+at::Tensor vector_spmm_forward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                               const at::Tensor& indices, const at::Tensor& edata, const at::Tensor& x) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(indices); CHECK_INPUT(edata); CHECK_INPUT(x);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid); CHECK_INDEX(indices);
+  DeviceGuard dg(x);
+  const int64_t h = edata.dim() == 2 ? edata.size(1) : 1, d = x.size(-1);   // graphop_kernel.cu:520
+  auto y = at::empty_like(x);                                               // zeros_like(x), :527
+  const auto& p = get_plan(row, indptr, eid, indices, x.size(0));
+  check(graphop_vector_spmm_forward(dtype_code(x), ip(row), ip(indptr), ip(eid), ip(indices), vp(edata), vp(x), vp(y),
+                                    row.size(0), eid.size(0), x.size(0), x.size(0), h, d, p.plan, stream_of(x)));
+  return y;
+}
+
+std::vector<at::Tensor> vector_spmm_backward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                             const at::Tensor& indices, const at::Tensor& col,
+                                             const at::Tensor& indptr_t, const at::Tensor& eid_t,
+                                             const at::Tensor& indices_t, const at::Tensor& edata,
+                                             const at::Tensor& dy, const at::Tensor& x) {   // NB dy before x, graphop.cpp:199-201
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(indices);
+  CHECK_INPUT(col); CHECK_INPUT(indptr_t); CHECK_INPUT(eid_t); CHECK_INPUT(indices_t);
+  CHECK_INPUT(edata); CHECK_INPUT(dy); CHECK_INPUT(x);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid); CHECK_INDEX(indices);
+  CHECK_INDEX(col); CHECK_INDEX(indptr_t); CHECK_INDEX(eid_t); CHECK_INDEX(indices_t);
+  DeviceGuard dg(x);
+  const int64_t h = edata.dim() == 2 ? edata.size(1) : 1, d = x.size(-1);
+  auto dedata = at::empty_like(edata), dx = at::empty_like(x);
+  const auto& pr = get_plan(row, indptr, eid, indices, x.size(0));
+  const auto& pc = get_plan(col, indptr_t, eid_t, indices_t, dy.size(0));
+  check(graphop_vector_spmm_backward(dtype_code(x), ip(row), ip(indptr), ip(eid), ip(indices), ip(col), ip(indptr_t),
+                                     ip(eid_t), ip(indices_t), vp(edata), vp(dy), vp(x), vp(dedata), vp(dx),
+                                     row.size(0), col.size(0), eid.size(0), x.size(0), dy.size(0), h, d, pr.plan,
+                                     pc.plan, stream_of(x)));
+  return {dedata, dx};   // graphop_kernel.cu:599
+}
+
+// ---- the extra fused op (include/graphop_hip.h: graphop_attention_*) ------------------------------
+std::vector<at::Tensor> attention_forward(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
+                                          const at::Tensor& indices, const at::Tensor& Q, const at::Tensor& K,
+                                          const at::Tensor& V) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr); CHECK_INPUT(eid); CHECK_INPUT(indices); CHECK_INPUT(Q); CHECK_INPUT(K); CHECK_INPUT(V);
+  CHECK_INDEX(row); CHECK_INDEX(indptr); CHECK_INDEX(eid); CHECK_INDEX(indices);
+  TORCH_CHECK(K.sizes() == V.sizes() && Q.sizes().slice(1) == K.sizes().slice(1),
+              "attention_forward: Q (n_q,[h,]d), K and V (n_k,[h,]d) expected");
+  DeviceGuard dg(Q);
+  const int64_t e = eid.size(0), d = Q.size(-1), h = Q.dim() == 2 ? 1 : Q.size(1), n_q = Q.size(0), n_k = K.size(0);
+  auto o = at::empty_like(Q);
+  auto stats = at::empty({n_q, h, 2}, Q.options());
+  const auto& p = get_plan(row, indptr, eid, indices, n_k);
+  int64_t nbytes = 0;
+  check(graphop_attention_workspace_bytes(dtype_code(Q), 0, e, n_q, n_k, h, d, p.plan, nullptr, stream_of(Q), &nbytes));
+  auto ws = at::empty({std::max<int64_t>(nbytes, 1)}, Q.options().dtype(at::kByte));
+  check(graphop_attention_forward(dtype_code(Q), ip(row), ip(indptr), ip(eid), ip(indices), vp(Q), vp(K), vp(V), vp(o),
+                                  vp(stats), row.size(0), e, n_q, n_k, h, d, ws.data_ptr(), nbytes, p.plan, stream_of(Q)));
+  return {o, stats};
+}
+
+std::vector<at::Tensor> attention_backward(const at::Tensor& row, const at::Tensor& indptr_r, const at::Tensor& eid_r,
+                                           const at::Tensor& indices_r, const at::Tensor& col,
+                                           const at::Tensor& indptr_c, const at::Tensor& eid_c,
+                                           const at::Tensor& indices_c, const at::Tensor& Q, const at::Tensor& K,
+                                           const at::Tensor& V, const at::Tensor& o, const at::Tensor& stats,
+                                           const at::Tensor& dO_) {
+  CHECK_INPUT(row); CHECK_INPUT(indptr_r); CHECK_INPUT(eid_r); CHECK_INPUT(indices_r);
+  CHECK_INPUT(col); CHECK_INPUT(indptr_c); CHECK_INPUT(eid_c); CHECK_INPUT(indices_c);
+  CHECK_INPUT(Q); CHECK_INPUT(K); CHECK_INPUT(V); CHECK_INPUT(o); CHECK_INPUT(stats);
+  CHECK_CUDA(dO_);
+  const at::Tensor dO = dO_.contiguous();
+  DeviceGuard dg(Q);
+  const int64_t e = eid_r.size(0), d = Q.size(-1), h = Q.dim() == 2 ? 1 : Q.size(1), n_q = Q.size(0), n_k = K.size(0);
+  TORCH_CHECK(o.sizes() == Q.sizes() && dO.sizes() == Q.sizes() && stats.numel() == n_q * h * 2,
+              "attention_backward: o, dO must match Q and stats must be (n_q, h, 2)");
+  auto dQ = at::empty_like(Q), dK = at::empty_like(K), dV = at::empty_like(V);
+  const auto& pr = get_plan(row, indptr_r, eid_r, indices_r, n_k);
+  const auto& pc = get_plan(col, indptr_c, eid_c, indices_c, n_q);
+  int64_t nbytes = 0;
+  check(graphop_attention_workspace_bytes(dtype_code(Q), 1, e, n_q, n_k, h, d, pr.plan, pc.plan, stream_of(Q), &nbytes));
+  auto ws = at::empty({std::max<int64_t>(nbytes, 1)}, Q.options().dtype(at::kByte));
+  check(graphop_attention_backward(dtype_code(Q), ip(row), ip(indptr_r), ip(eid_r), ip(indices_r), ip(col), ip(indptr_c),
+                                   ip(eid_c), ip(indices_c), vp(Q), vp(K), vp(V), vp(o), vp(stats), vp(dO), vp(dQ),
+                                   vp(dK), vp(dV), row.size(0), col.size(0), e, n_q, n_k, h, d, ws.data_ptr(), nbytes,
+                                   pr.plan, pc.plan, stream_of(Q)));
+  return {dQ, dK, dV};
+}
+
+void clear_plan_cache() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_plans) graphop_plan_destroy(kv.second.plan);
+  g_plans.clear();
+  g_lru.clear();
+}
+
+// ---- registration 1: the reference's pybind11 module (graphop.cpp:216-225) ------------------------------
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("maskedmm_csr_forward", &maskedmm_csr_forward, "Masked Matrix Multiplication forward(CSR Format)");
+  m.def("maskedmm_csr_backward", &maskedmm_csr_backward, "Masked Matrix Multiplication backward(CSR Format)");
+  m.def("node_mul_edge_forward", &node_mul_edge_forward, "Node Multiply Edge forward");
+  m.def("node_mul_edge_backward", &node_mul_edge_backward, "Node Multiply Edge backward");
+  m.def("sparse_softmax_forward", &sparse_softmax_forward, "Sparse softmax forward");
+  m.def("sparse_softmax_backward", &sparse_softmax_backward, "Sparse softmax backward");
+  m.def("vector_spmm_forward", &vector_spmm_forward, "Vectorized SPMM forward");
+  m.def("vector_spmm_backward", &vector_spmm_backward, "Vectorized SPMM backward");
+  m.def("attention_forward", &attention_forward, "Fused SDDMM -> softmax -> SpMM forward (extra op)");
+  m.def("attention_backward", &attention_backward, "Fused attention backward (extra op)");
+  m.def("clear_plan_cache", &clear_plan_cache, "Destroy every cached per-graph plan");
+}
+
+// ---- registration 2: torch.ops.graphop.* (schemas + CUDA(HIP) implementations) ------------------------------
+TORCH_LIBRARY(graphop, m) {
+  m.def("maskedmm_csr_forward(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor A, Tensor B) -> Tensor");
+  m.def("maskedmm_csr_backward(Tensor row, Tensor indptr_r, Tensor eid_r, Tensor indices_r, Tensor col, Tensor indptr_c, Tensor eid_c, Tensor indices_c, Tensor A, Tensor B, Tensor dy) -> Tensor[]");
+  m.def("node_mul_edge_forward(Tensor row, Tensor indptr, Tensor eid, Tensor A, Tensor B) -> Tensor");
+  m.def("node_mul_edge_backward(Tensor row, Tensor indptr, Tensor eid, Tensor A, Tensor B, Tensor dy) -> Tensor[]");
+  m.def("sparse_softmax_forward(Tensor row, Tensor indptr, Tensor eid, Tensor x) -> Tensor");
+  m.def("sparse_softmax_backward(Tensor row, Tensor indptr, Tensor eid, Tensor y, Tensor dy) -> Tensor");
+  m.def("vector_spmm_forward(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor edata, Tensor x) -> Tensor");
+  m.def("vector_spmm_backward(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor col, Tensor indptr_t, Tensor eid_t, Tensor indices_t, Tensor edata, Tensor dy, Tensor x) -> Tensor[]");
+  m.def("attention_forward(Tensor row, Tensor indptr, Tensor eid, Tensor indices, Tensor Q, Tensor K, Tensor V) -> Tensor[]");
+  m.def("attention_backward(Tensor row, Tensor indptr_r, Tensor eid_r, Tensor indices_r, Tensor col, Tensor indptr_c, Tensor eid_c, Tensor indices_c, Tensor Q, Tensor K, Tensor V, Tensor o, Tensor stats, Tensor dO) -> Tensor[]");
+}
+
+TORCH_LIBRARY_IMPL(graphop, CUDA, m) {
+  m.impl("maskedmm_csr_forward", &maskedmm_csr_forward);
+  m.impl("maskedmm_csr_backward", &maskedmm_csr_backward);
+  m.impl("node_mul_edge_forward", &node_mul_edge_forward);
+  m.impl("node_mul_edge_backward", &node_mul_edge_backward);
+  m.impl("sparse_softmax_forward", &sparse_softmax_forward);
+  m.impl("sparse_softmax_backward", &sparse_softmax_backward);
+  m.impl("vector_spmm_forward", &vector_spmm_forward);
+  m.impl("vector_spmm_backward", &vector_spmm_backward);
+  m.impl("attention_forward", &attention_forward);
+  m.impl("attention_backward", &attention_backward);
+}
+
+TORCH_LIBRARY_IMPL(graphop, CPU, m) {   // there is no CPU implementation: the reference's CHECK_CUDA message
+  m.impl("maskedmm_csr_forward", &maskedmm_csr_forward);
+  m.impl("maskedmm_csr_backward", &maskedmm_csr_backward);
+  m.impl("node_mul_edge_forward", &node_mul_edge_forward);
+  m.impl("node_mul_edge_backward", &node_mul_edge_backward);
+  m.impl("sparse_softmax_forward", &sparse_softmax_forward);
+  m.impl("sparse_softmax_backward", &sparse_softmax_backward);
+  m.impl("vector_spmm_forward", &vector_spmm_forward);
+  m.impl("vector_spmm_backward", &vector_spmm_backward);
+  m.impl("attention_forward", &attention_forward);
+  m.impl("attention_backward", &attention_backward);
+}

@@ -364,10 +364,21 @@ def _cpu_refusal(name):
     return _impl
 
 
+cpp_ext = None      # the compiled extension module (csrc/torch_ext.cpp) when it is built, else None
+
+
 def register_torch_ops():
-    """Define torch.ops.graphop.* once (CUDA key -> the HIP ops above, CPU key -> error)."""
-    global _torch_lib
+    """Define torch.ops.graphop.* once.  If the compiled C++ extension graphop_cpp is built, loading
+    it registers the namespace from C++ (TORCH_LIBRARY(graphop), csrc/torch_ext.cpp: the reference-style
+    boundary over the same C ABI); otherwise the ops are defined here (CUDA key -> the ctypes-bound
+    functions above, CPU key -> error)."""
+    global _torch_lib, cpp_ext
     if _torch_lib is not None:
+        return
+    from . import _ext
+    cpp_ext = _ext.load()
+    if cpp_ext is not None:
+        _torch_lib = cpp_ext
         return
     l = torch.library.Library("graphop", "DEF")
     g = globals()

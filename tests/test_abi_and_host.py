@@ -68,7 +68,7 @@ def test_cpu_tensors_are_refused_like_the_reference():
         graphop.sparse_softmax_forward(i, i, i, f[:, 0].contiguous())
     with pytest.raises(RuntimeError, match="row must be a CUDA tensor"):
         graphop.vector_spmm_backward(i, i, i, i, i, i, i, i, f, f, f)
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
+    with pytest.raises(RuntimeError, match="no CPU implementation|must be a CUDA tensor"):
         torch.ops.graphop.sparse_softmax_forward(i, i, i, f[:, 0].contiguous())
 
 
@@ -169,3 +169,28 @@ def test_container_reads_format_1(tmp_path):
     p = str(tmp_path / "old.pt")
     torch.save(payload, p)
     assert torch.equal(graphs.load_graph(p).eid_c, g.eid_c)
+
+
+def test_cpp_extension_mirrors_the_reference_module():
+    """csrc/torch_ext.cpp, built by __graft_entry__.build(): a compiled PyTorch C++ extension with the
+    reference's eight pybind11 functions (graphop.cpp:216-225) AND TORCH_LIBRARY(graphop); CHECK_CUDA /
+    CHECK_CONTIGUOUS raise the reference's messages (graphop.cpp:4-6) before anything touches a device."""
+    from custom_op_benchmark_amd import _ext, graphop
+    ext = _ext.load()
+    if ext is None:
+        pytest.skip("graphop_cpp.so not built (run __graft_entry__.build())")
+    names = ["maskedmm_csr_forward", "maskedmm_csr_backward", "node_mul_edge_forward", "node_mul_edge_backward",
+             "sparse_softmax_forward", "sparse_softmax_backward", "vector_spmm_forward", "vector_spmm_backward"]
+    for n in names + ["attention_forward", "attention_backward"]:
+        assert callable(getattr(ext, n)) and hasattr(torch.ops.graphop, n)
+    assert graphop.cpp_ext is ext                      # torch.ops.graphop.* was registered from C++
+    i = torch.zeros(2, dtype=torch.int64)
+    f = torch.zeros(2, 4)
+    with pytest.raises(RuntimeError, match="row must be a CUDA tensor"):
+        ext.maskedmm_csr_forward(i, i, i, i, f, f)
+    with pytest.raises(RuntimeError, match="row must be a CUDA tensor"):
+        ext.vector_spmm_backward(i, i, i, i, i, i, i, i, f, f, f)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        torch.ops.graphop.attention_forward(i, i, i, i, f, f, f)
+    with pytest.raises(TypeError):
+        ext.sparse_softmax_forward(i, i, i)            # positional signature, 4 arguments (graphop.cpp:59-63)
