@@ -39,8 +39,9 @@ python bench.py --graph harness --d 64 --heads 8 --steps 50 --warmup 5 --no-cpu-
 python bench.py --graph cora --steps 50 --warmup 5 > "$OUT/${TAG}_cora_bench.json" 2>/dev/null
 python bench.py --graph cora --steps 50 --warmup 5 --no-cpu-baseline --hip-graph > "$OUT/${TAG}_cora_hipgraph_bench.json" 2>/dev/null
 echo "[refresh] small shapes done"
+python tools/tune_sweep.py --fused "" > "$OUT/${TAG}_fused_passes.txt" 2>/dev/null
 python bench.py --graph products --d 16 --heads 8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d16_bench.json" 2>/dev/null
-python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --cpu-sample-edges 1500000 > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
+python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --cpu-sample-edges 200000 > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
 echo "[refresh] products done"
 # one-GPU rehearsal of rank 0's shard of the 8-way multi-GPU configs (timing only: exchanges = local copies)
 python bench.py --emulate-world 8 --graph papers100m --steps 5 --warmup 2 > "$OUT/${TAG}_emulate8_papers100m_bench.json" 2>/dev/null
