@@ -73,6 +73,7 @@ _SIGNATURES = {
     "graphop_node_mul_edge_backward": [ctypes.c_int] + [_P] * 8 + [_c64] * 5 + [_P, _P],
     "graphop_gather_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_scatter_add_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
+    "graphop_add_rows_unique": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_attention_workspace_bytes": [ctypes.c_int, ctypes.c_int] + [_c64] * 5 + [_P, _P, _P,
                                                                                        ctypes.POINTER(_c64)],
     "graphop_attention_backward_is_fused": [ctypes.c_int] + [_c64] * 5 + [_P, _P, _P, ctypes.POINTER(ctypes.c_int)],
@@ -425,10 +426,20 @@ def gather_rows(src, idx, out=None):
     return out
 
 
-def scatter_add_rows(dst, idx, src):
-    """dst[idx[i]] += src[i] in place (idx may repeat)."""
+def scatter_add_rows(dst, idx, src, unique_runs=None):
+    """dst[idx[i]] += src[i] in place.  idx may repeat -> float atomics; with unique_runs = the
+    lengths of consecutive idx runs that hold no repeats (the rows served to each peer) the runs are
+    added one after the other with plain read-add-write kernels."""
     row = dst[0].numel() if dst.size(0) else 0
     with torch.cuda.device(dst.device):
-        check(lib().graphop_scatter_add_rows(dtype_code(dst), ptr(src), ptr(idx), ptr(dst), idx.numel(),
-                                             dst.size(0), row, stream_of(dst)))
+        if unique_runs is None:
+            check(lib().graphop_scatter_add_rows(dtype_code(dst), ptr(src), ptr(idx), ptr(dst), idx.numel(),
+                                                 dst.size(0), row, stream_of(dst)))
+        else:
+            o = 0
+            for n in unique_runs:
+                if n:
+                    check(lib().graphop_add_rows_unique(dtype_code(dst), ptr(src[o:o + n]), ptr(idx[o:o + n]),
+                                                        ptr(dst), n, dst.size(0), row, stream_of(dst)))
+                o += n
     return dst

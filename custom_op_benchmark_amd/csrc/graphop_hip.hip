@@ -1010,13 +1010,15 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
     GO_TRY(check_rows(fn, "A / dA", pr, n_a)); GO_TRY(check_cols(fn, "B", pr, n_b));
     GO_TRY(check_rows(fn, "B / dB", pc, n_b)); GO_TRY(check_cols(fn, "A", pc, n_a));
   }
-  if (n_a * h * d > 0) {
+  // an output whose orientation has no chunks may be NULL: that half of the op is skipped entirely
+  // (the sharded step calls the op once per orientation to overlap the dK exchange, dist.py)
+  if (n_a * h * d > 0 && !(dA == nullptr && n_row_chunks == 0)) {
     GO_PTR(fn, dA);
     if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r,
                                n_row_chunks, n_edges, plan_r, n_b, B, dA, h, d, n_a))
       GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st));
   }
-  if (n_b * h * d > 0) {
+  if (n_b * h * d > 0 && !(dB == nullptr && n_col_chunks == 0)) {
     GO_PTR(fn, dB);
     if (!spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c,
                                n_col_chunks, n_edges, plan_c, n_a, A, dB, h, d, n_b))

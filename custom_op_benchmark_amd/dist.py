@@ -266,7 +266,8 @@ class ShardedAttention:
         """Partial gradient rows that came home += into the owners' rows (serve_rows may repeat)."""
         if dX_own.is_cuda and self.ops is None and dX_own.is_contiguous():
             from . import _lib
-            _lib.scatter_add_rows(dX_own, self.serve_rows, recv)
+            # the rows served to ONE peer are distinct (its halo ids are unique): one plain-add kernel per peer
+            _lib.scatter_add_rows(dX_own, self.serve_rows, recv, unique_runs=self.send_counts)
         else:
             dX_own.index_add_(0, self.serve_rows, recv)
         return dX_own
@@ -324,8 +325,10 @@ class ShardedAttention:
         s = ops.maskedmm_csr_forward(*a4, Qd, K_ext)
         a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
         wait_v.wait()
-        o_ext = ops.vector_spmm_forward(*a4, a, V_ext)          # (n_ext, ...) ; rows >= n_own are 0
-        o = o_ext[:n_own]
+        if self.ops is None and V_ext.is_cuda:
+            o = self._spmm_forward_own_rows(a, V_ext)           # C ABI: n_y = n_own rows, no zero fill of the halo part
+        else:
+            o = ops.vector_spmm_forward(*a4, a, V_ext)[:n_own]  # reference surface: y = zeros_like(x), rows >= n_own are 0
         # dy is only indexed by row ids (< n_own): no need to pad it to the extended row count
         da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
         # backward exchange: partial rows computed for halo columns go home and are added there;
@@ -340,12 +343,19 @@ class ShardedAttention:
             # home, then the row-major half (dQ) runs under that exchange.  Each half is the same
             # entry point with the other orientation's chunk list empty.
             er, ep = self._empty_chunks()
-            _, dK_ext = ops.maskedmm_csr_backward(er, ep, g.eid_r, g.indices_r, g.col, g.ptr_c, g.eid_c,
-                                                  g.indices_c, Qd, K_ext, ds)
+            hip = self.ops is None and K_ext.is_cuda
+            if hip:
+                dK_ext = self._sddmm_backward_half(Qd, K_ext, ds, col_half=True)
+            else:
+                _, dK_ext = ops.maskedmm_csr_backward(er, ep, g.eid_r, g.indices_r, g.col, g.ptr_c, g.eid_c,
+                                                      g.indices_c, Qd, K_ext, ds)
             dK = dK_ext[:n_own]
             wait_dk, recv_dk = self.scatter_halo_grad_start(dK, dK_ext[n_own:], async_op=True, role="dK")
-            dQ, _ = ops.maskedmm_csr_backward(g.row, g.ptr_r, g.eid_r, g.indices_r, er, ep, g.eid_c,
-                                              g.indices_c, Qd, K_ext, ds)
+            if hip:
+                dQ = self._sddmm_backward_half(Qd, K_ext, ds, col_half=False)
+            else:
+                dQ, _ = ops.maskedmm_csr_backward(g.row, g.ptr_r, g.eid_r, g.indices_r, er, ep, g.eid_c,
+                                                  g.indices_c, Qd, K_ext, ds)
             wait_dk.wait()
             self._add_home(dK, recv_dk)
             wait_dv.wait()
@@ -361,6 +371,49 @@ class ShardedAttention:
             if t.requires_grad:
                 t.grad = gr
         return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    # ---- C-ABI calls the reference's Python surface cannot express (HIP path only) -----------------
+    def _spmm_forward_own_rows(self, a, V_ext):
+        """vector_spmm_forward with n_y = n_own output rows (the reference returns zeros_like(x):
+        n_own + n_halo rows, of which the halo part is only ever zero-filled)."""
+        from . import _lib
+        g = self.graph
+        h = a.size(1) if a.dim() == 2 else 1
+        o = V_ext.new_empty((self.n_own,) + tuple(V_ext.shape[1:]))
+        with _lib.device_guard(V_ext.device):
+            plan = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, V_ext.size(0))
+            _lib.check(_lib.lib().graphop_vector_spmm_forward(
+                _lib.dtype_code(V_ext), _lib.ptr(g.row), _lib.ptr(g.ptr_r), _lib.ptr(g.eid_r), _lib.ptr(g.indices_r),
+                _lib.ptr(a), _lib.ptr(V_ext), _lib.ptr(o), g.row.size(0), g.eid_r.size(0), V_ext.size(0), self.n_own,
+                h, V_ext.size(-1), plan.handle, _lib.stream_of(V_ext)))
+        return o
+
+    def _sddmm_backward_half(self, Q, K_ext, ds, col_half):
+        """One orientation of maskedmm_csr_backward: the other output is passed as NULL with an empty
+        chunk list, so it is neither allocated nor zero-filled."""
+        from . import _lib
+        g = self.graph
+        er, ep = self._empty_chunks()
+        ds = ds.contiguous()
+        h = ds.size(1) if ds.dim() == 2 else 1
+        L = _lib.lib()
+        with _lib.device_guard(Q.device):
+            if col_half:
+                out = torch.empty_like(K_ext)
+                plan_r = _lib.get_plan(er, ep, g.eid_r, g.indices_r, K_ext.size(0))
+                plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, Q.size(0))
+                row, ptr_r, col, ptr_c, dA, dB = er, ep, g.col, g.ptr_c, None, out
+            else:
+                out = torch.empty_like(Q)
+                plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, K_ext.size(0))
+                plan_c = _lib.get_plan(er, ep, g.eid_c, g.indices_c, Q.size(0))
+                row, ptr_r, col, ptr_c, dA, dB = g.row, g.ptr_r, er, ep, out, None
+            _lib.check(L.graphop_maskedmm_csr_backward(
+                _lib.dtype_code(Q), _lib.ptr(row), _lib.ptr(ptr_r), _lib.ptr(g.eid_r), _lib.ptr(g.indices_r),
+                _lib.ptr(col), _lib.ptr(ptr_c), _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(Q), _lib.ptr(K_ext),
+                _lib.ptr(ds), _lib.ptr(dA), _lib.ptr(dB), row.size(0), col.size(0), g.eid_r.size(0),
+                Q.size(0), K_ext.size(0), h, Q.size(-1), plan_r.handle, plan_c.handle, _lib.stream_of(Q)))
+        return out
 
     def _empty_chunks(self):
         """(row[0], indptr[1] = [0]): a chunk list that covers nothing (int64, on this shard's device)."""

@@ -200,7 +200,9 @@ GRAPHOP_API int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, cons
  *                            A, B, dy) -> [dA, dB]
  * replaces graphop.cpp:108-131 / graphop_kernel.cu:355-409 (kernel :100-112, launched twice).
  * dA[row[c]]  += sum_k dy[eid_r[k]] * B[indices_r[k]]   (row-major CSR)
- * dB[col[c]]  += sum_k dy[eid_c[k]] * A[indices_c[k]]   (column-major CSR) */
+ * dB[col[c]]  += sum_k dy[eid_c[k]] * A[indices_c[k]]   (column-major CSR)
+ * dA may be NULL when n_row_chunks == 0, dB when n_col_chunks == 0 (that half is skipped: the op can
+ * be run one orientation at a time). */
 GRAPHOP_API int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* indptr_r,
                                   const int64_t* eid_r, const int64_t* indices_r,
                                   const int64_t* col, const int64_t* indptr_c,
@@ -319,6 +321,11 @@ GRAPHOP_API int graphop_attention_backward(int dtype, const int64_t* row, const 
  *                   the caller built them from its own range, custom_op_benchmark_amd/dist.py). */
 GRAPHOP_API int graphop_gather_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
                         int64_t n_src_rows, int64_t row_elems, void* stream);
+/* add_rows_unique: the same as scatter_add_rows for an idx run WITHOUT repeats (the rows served to ONE
+ * peer are distinct): plain read-add-write at streaming rate instead of memory-side atomics; runs for
+ * different peers must be issued one after the other on the same stream. */
+GRAPHOP_API int graphop_add_rows_unique(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
+                            int64_t n_dst_rows, int64_t row_elems, void* stream);
 GRAPHOP_API int graphop_scatter_add_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
                              int64_t n_dst_rows, int64_t row_elems, void* stream);
 
