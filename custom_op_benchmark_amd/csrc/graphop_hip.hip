@@ -250,6 +250,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
     out->view.K = K;
     out->view.win_bytes = win_cols * row_bytes;
     out->view.table_bytes = table_bytes;
+    out->view.touch = opts ? opts->touch : 0;
     if (!dry && zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
     i64 nb = (i64)t.n_cu * bpc;
     const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
@@ -302,6 +303,7 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   SweepLaunch sl;
   SweepOpts so;
   so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  so.touch = tuning().touch_sddmm;
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
   if (use != 1) return use;
   ProfScope prof(tag, st, sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
@@ -743,7 +745,8 @@ int graphop_tune(const char* key, int value) {
       {"sweep_mode", &t.sweep_mode}, {"sweep_w", &t.sweep_w}, {"spmm_window_scale", &t.spmm_window_scale}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
-      {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc}};
+      {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
+      {"touch_sddmm", &t.touch_sddmm}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;

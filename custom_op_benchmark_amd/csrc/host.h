@@ -42,6 +42,7 @@ struct Tuning {
   int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
   int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
   int attn_bpc;           // resident workgroups per CU of the fused kernels
+  int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -66,6 +67,7 @@ struct Tuning {
     attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
+    touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -108,6 +110,7 @@ struct SweepOpts {
   int bpc = 0;            // resident workgroups per CU (0 = tuning().sweep_bpc)
   int require_owner = 0;  // 1: only the window-owner order is acceptable (return 0 otherwise)
   int dry_run = 0;        // 1: decide and build the cached structure only (no task queue is taken)
+  int touch = 0;          // SweepView::touch of the launch
 };
 
 // Decide whether the window-sweep driver applies and fetch / build its structure.

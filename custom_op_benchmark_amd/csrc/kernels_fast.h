@@ -334,6 +334,33 @@ __global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
 }
 
 
+// Touch the 128-B lines of this lane's granule [lo, lo + n) of a 4-byte stream (ids, edge ids,
+// row-major weights) so that the per-batch loads of the strip find them in L2.  Vector-memory loads
+// return in issue order: a per-batch id load that misses L2 holds back the 16 row loads issued
+// behind it for an HBM latency (tools/microbench/l2_gather_ids.hip: 23 TB/s of row gathers with the
+// ids streamed from HBM, 30.5 TB/s with an L2-resident id stream).  Issued once per task, in front
+// of the first id load the strip has to wait for anyway, the misses of a whole granule overlap.
+// Measured on Reddit-shape: SDDMM-type passes 1.79-1.84 -> 1.73-1.75 ms; the SpMM-type and fused
+// passes (windows of twice the L2 size: the touched lines evict rows) got 3-7 % SLOWER, so only the
+// SDDMM strip uses it (tuning knob touch_sddmm).
+// Covers granules of up to ~65 slots (three lines); longer ones keep some cold lines (speed only).
+// The values must be `retire`d at the end of the strip (keeps the landing registers reserved).
+struct LineTouch {
+  int a, b, c;
+  template <typename T>
+  __device__ __forceinline__ void issue(const T* __restrict__ base, int lo, int n) {
+    static_assert(sizeof(T) == 4, "4-byte streams");
+    a = b = c = 0;
+    if (n > 0) {
+      const int* p = reinterpret_cast<const int*>(base);
+      a = p[lo];
+      b = p[lo + (n >> 1)];
+      c = p[lo + n - 1];
+    }
+  }
+  __device__ __forceinline__ void retire() const { asm volatile("; touched %0 %1 %2" ::"v"(a), "v"(b), "v"(c)); }
+};
+
 // ---- STRIP inner loops (window-sweep drivers) -----------------------------------------------------
 // A strip is what one lane group does in one window: lane k < nv owns granule k = slots
 // [lo_l, lo_l + n_l) of its vrow k.  The K granules are walked as ONE flat slot list in full
@@ -384,13 +411,17 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
                                             const int* __restrict__ eid32,
                                             const int* __restrict__ idx32,
                                             const float* __restrict__ B, float* __restrict__ y,
-                                            int h, int d4, int l, Stage&& stage_rows = Stage()) {
+                                            int h, int d4, int l, Stage&& stage_rows = Stage(),
+                                            int touch = 0) {
   constexpr int SB = StripCfg<L, NV>::SB;
   constexpr i64 F4 = (i64)L * NV;
   StripMap m;
   m.init<L>(lo_l, n_l, l);
   if (m.total == 0) return;
   float4 a[NV];
+  LineTouch t_idx, t_eid;
+  t_idx.issue(idx32, lo_l, (touch & 1) ? n_l : 0);
+  if constexpr (!EID_ID) t_eid.issue(eid32, lo_l, (touch & 2) ? n_l : 0);
   // prefetch batch 0
   int nk = 0, ne = -1, nsrc = 0;
   {
@@ -491,6 +522,8 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
   if constexpr (H1) {
     if (prev_e >= 0) y[prev_e] = prev_res;
   }
+  t_idx.retire();
+  if constexpr (!EID_ID) t_eid.retire();
 }
 
 // `sink(k, acc)` receives the finished partial sum of granule k (group-uniform call).
@@ -624,6 +657,7 @@ struct SweepView {
   i64 win_bytes;      // bytes of gathered table per window
   i64 table_bytes;    // bytes of the gathered table
   int prefetch;       // 1: every workgroup touches a slice of the NEXT window at the start of a step
+  int touch;          // bit 0: touch the granule's id lines at task start, bit 1: also its edge-id / weight lines
 };
 
 // Soft pacing between the workgroups of one sweep launch, per XCD (each XCD has its own L2, so
@@ -972,7 +1006,7 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_sddmm_w
       }
     };
     sddmm_strip<L, NV, H1, EID_ID, OFF32>(mine, cur.lo, cur.hi - cur.lo, s.eid32, s.idx32, B, y, h, d4, l,
-                                          stage_rows);
+                                          stage_rows, s.touch);
     cur = nxt;
     more = more_n;
   }

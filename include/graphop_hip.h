@@ -90,7 +90,8 @@ GRAPHOP_API const char* graphop_last_error(void);
  * sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift, sweep_min_granule, sweep_prefetch,
  * transpose_scalars, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
  * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile), attn_fused (0/1),
- * attn_window_scale, attn_k, attn_bpc (fused attention kernels).  Not
+ * attn_window_scale, attn_k, attn_bpc (fused attention kernels), touch_sddmm (per-task id-line
+ * touches of the SDDMM strips).  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
 
