@@ -226,3 +226,46 @@ def test_fused_step_replays_from_a_hip_graph(dev, force_sweep):
     torch.testing.assert_close(o.detach(), eager["o"], rtol=1e-5, atol=1e-6)
     for key, got in (("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
         torch.testing.assert_close(got, eager[key], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_fused_fuzz_shapes_and_paths(dev, seed):
+    """Randomised battery for the fused op: width, heads, chunk size, degree profile, square /
+    non-square, windows forced on (random window size, piece length, K, resident grid, touch knob) or
+    off.  Fused passes or composed path, whichever applies -- always vs the oracle."""
+    import numpy as np
+    rng = np.random.RandomState(4000 + seed)
+    h = int(rng.choice([1, 1, 1, 2, 8]))
+    d = int(rng.choice([4, 16, 64])) if h > 1 else int(rng.choice([16, 32, 64, 128, 256]))
+    n_src = int(rng.randint(40, 900))
+    n_dst = n_src if rng.rand() < 0.5 else int(rng.randint(40, 900))
+    n_edges = int(rng.randint(1, 40) * n_src)
+    cs = int(rng.choice([1, 7, 32, 64]))
+    hub = int(rng.choice([0, 0, 300, 1500]))
+    forced = bool(rng.rand() < 0.7)
+    knobs = {}
+    if forced:
+        knobs = dict(sweep_min_kb=0, sweep_min_granule=0, max_windows=512, window_kb=int(rng.choice([1, 4, 16])),
+                     vrow_t=int(rng.choice([0, 64, 256])), attn_window_scale=int(rng.choice([1, 2, 4])),
+                     attn_k=int(rng.choice([0, 1, 2, 4])), attn_bpc=int(rng.choice([0, 1, 2])),
+                     touch_sddmm=int(rng.choice([0, 1, 3])))
+    for k, v in knobs.items():
+        _lib.tune(k, v)
+    _lib.clear_plan_cache()
+    try:
+        g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
+                         hub=hub or None)
+        inp = rand_inputs(g, h, d, seed=seed + 50, normal=True)
+        dO = inp["dO"][:g.n_src] if g.n_dst >= g.n_src else torch.cat([inp["dO"], inp["Q"][g.n_dst:]])[:g.n_src]
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], dO)
+        want["o"] = want["o"][:g.n_src] if want["o"].size(0) >= g.n_src else want["o"]
+        if g.n_dst < g.n_src:
+            pytest.skip("the oracle's y = zeros_like(x) cannot hold n_src > n_dst output rows")
+        got = fused_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V")), dO.to(dev))
+        for key in ("o", "dQ", "dK", "dV"):
+            close(got[key], want[key], rtol=2e-4, atol=2e-5)
+    finally:
+        for k, v in dict(sweep_min_kb=4608, sweep_min_granule=4, max_windows=128, window_kb=4096, vrow_t=0,
+                         attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1).items():
+            _lib.tune(k, v)
+        _lib.clear_plan_cache()
