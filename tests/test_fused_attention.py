@@ -255,12 +255,13 @@ def test_fused_fuzz_shapes_and_paths(dev, seed):
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
                          hub=hub or None)
-        inp = rand_inputs(g, h, d, seed=seed + 50, normal=True)
-        dO = inp["dO"][:g.n_src] if g.n_dst >= g.n_src else torch.cat([inp["dO"], inp["Q"][g.n_dst:]])[:g.n_src]
-        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], dO)
-        want["o"] = want["o"][:g.n_src] if want["o"].size(0) >= g.n_src else want["o"]
+        # the oracle's SpMM output is zeros_like(x) (graphop_kernel.cu:527): x (n_dst rows) must cover the row ids
         if g.n_dst < g.n_src:
-            pytest.skip("the oracle's y = zeros_like(x) cannot hold n_src > n_dst output rows")
+            g = random_graph(n_src, n_src, n_edges, seed=seed, chunk_size=cs, hub=hub or None)
+        inp = rand_inputs(g, h, d, seed=seed + 50, normal=True)
+        dO = inp["dO"][:g.n_src]
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], dO)
+        want["o"] = want["o"][:g.n_src]
         got = fused_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V")), dO.to(dev))
         for key in ("o", "dQ", "dK", "dV"):
             close(got[key], want[key], rtol=2e-4, atol=2e-5)
