@@ -134,6 +134,11 @@ def vector_spmm_forward(row, indptr, eid, indices, edata, x):
     h = edata.size(1) if edata.dim() == 2 else 1               # :520
     d = x.size(-1)
     y = torch.empty_like(x)                                    # zeros_like(x), :527
+    # the reference writes y[row[c]] without a bound (it assumes #rows == #x rows): as a checker,
+    # refuse the shapes for which that is an out-of-bounds write instead of corrupting the heap
+    if row.numel() and int(row.max()) >= x.size(0):
+        raise ValueError("oracle.vector_spmm_forward: row id %d but y = zeros_like(x) has %d rows"
+                         % (int(row.max()), x.size(0)))
     getattr(lib(), "oracle_vector_spmm_forward_" + _suf(x))(
         _p(row), _p(indptr), _p(eid), _p(indices), _p(edata), _p(x), _p(y),
         _i(row.size(0)), _i(x.size(0)), _i(d), _i(h))
