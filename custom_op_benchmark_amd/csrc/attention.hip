@@ -59,13 +59,16 @@ int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const
   return (use_r == 1 && use_c == 1) ? 1 : 0;
 }
 
+// Workspace layouts: byte offsets first (the size queries pass no buffer), pointers only from a real base.
+inline char* at_offset(char* base, size_t off) { return base ? base + off : nullptr; }
+
 struct FastWs {
   float* kv; float* qdo; float4* st4; size_t total;
   FastWs(char* base, i64 n_q, i64 n_k, i64 F) {
     size_t off = 0;
-    kv = (float*)(base + off); off += align_up(sizeof(float) * (size_t)(n_k * 2 * F));
-    qdo = (float*)(base + off); off += align_up(sizeof(float) * (size_t)(n_q * 2 * F));
-    st4 = (float4*)(base + off); off += align_up(sizeof(float4) * (size_t)n_q);
+    kv = (float*)at_offset(base, off); off += align_up(sizeof(float) * (size_t)(n_k * 2 * F));
+    qdo = (float*)at_offset(base, off); off += align_up(sizeof(float) * (size_t)(n_q * 2 * F));
+    st4 = (float4*)at_offset(base, off); off += align_up(sizeof(float4) * (size_t)n_q);
     total = off;
   }
 };
@@ -76,10 +79,10 @@ struct SlowWs {
   SlowWs(char* base, int n_arrays, size_t es, i64 E, i64 h, i64 soft_rows) {
     size_t off = 0;
     for (int i = 0; i < 4; ++i) {
-      arr[i] = base + off;
+      arr[i] = at_offset(base, off);
       if (i < n_arrays) off += align_up(es * (size_t)(E * h));
     }
-    soft = base + off; off += align_up(es * (size_t)(2 * soft_rows * h));
+    soft = at_offset(base, off); off += align_up(es * (size_t)(2 * soft_rows * h));
     total = off;
   }
 };
