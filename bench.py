@@ -439,6 +439,10 @@ def main():
                           + (" [TIMING-ONLY rehearsal of shard 0 of %d on one GPU, exchanges = local copies]" % args.emulate_world
                              if args.emulate_world > 1 and world == 1 else "")}
     if runner is not None:
+        cfg["weak_scaling_note"] = ("N > 1 runs BASELINE.json config %s (one 1/8 shard of the %s shape per GPU, fixed work per GPU); "
+                                    "the N = 1 default is the Reddit headline (config 2), a different workload: compare "
+                                    "N > 1 values among themselves and with `bench.py --gpus 1 --graph %s` (the same shard "
+                                    "without halo)" % ("4" if name == "papers100m" else "5" if name == "rmat25" else "?", name, name))
         cfg["halo"] = runner.halo_stats(h * d * 4)
         # per-exchange wall times, measured in a separate pass (their syncs defeat the overlap)
         runner.timers = {}
