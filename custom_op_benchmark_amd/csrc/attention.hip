@@ -1,10 +1,11 @@
 // Fused attention step (extra op next to the reference's eight):
 //   forward : o = vector_spmm(sparse_softmax(maskedmm_csr(Q, K)), V), leaving only o and the row
 //             statistics (max, 1 / sum) behind -- s and a live in the caller's workspace;
-//   backward: dQ, dK, dV from (Q, K, V, o, stats, dO) by two fused window-owner passes
-//             (kernels_attn.h) that recompute a and ds per slot; when those do not apply (no plan,
-//             unsorted rows, fp64, several heads, tiny tables) the same result comes from the
-//             composition of the unfused entry points, with the intermediates in the workspace.
+//   backward: dQ, dK, dV from (Q, K, V, o, stats, dO) by two fused passes (kernels_attn.h) that
+//             recompute a and ds per slot -- window-owner drivers where a sweepable plan and a table
+//             beyond the L2 make column windows pay, chunk drivers otherwise; when neither applies
+//             (no plan, fp64, several heads) the same result comes from the composition of the
+//             unfused entry points, with the intermediates in the workspace.
 // Reference composition: wrapper.py:20-30 (MaskedMMCSR), :8-18 (SparseSoftmax), :44-55 (VectorSPMM).
 #include "common.h"
 #include "host.h"
@@ -61,6 +62,49 @@ int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const
 
 // Workspace layouts: byte offsets first (the size queries pass no buffer), pointers only from a real base.
 inline char* at_offset(char* base, size_t off) { return base ? base + off : nullptr; }
+
+// The chunk-driver form of the fused passes (k_attn_bwd_rows_f32): any fp32 one-head graph with plans
+// (they carry the id ranges that make the gathers safe); no window structure needed.
+bool attn_rows_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const graphop_plan* plan_r,
+                  const graphop_plan* plan_c) {
+  const Tuning& t = tuning();
+  if (!t.attn_fused || !t.attn_rows || t.force_generic || dtype != GRAPHOP_F32 || h != 1) return false;
+  if (!plan_r || !plan_c || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024 || n_edges == 0) return false;
+  if (!plan_r->indices || !plan_c->indices) return false;
+  // Worth it only where the E-sized streams the fused passes avoid (~180 B per slot: two 64-B scalar
+  // gather sectors, four 16-B id pairs, da / ds) outweigh packing the two operand tables
+  // (16*F bytes of traffic per node, x1.5 margin).  Measured: products-shape d=16 (E/N = 25)
+  // 16.0 -> 9.5 ms per step; papers100M-shape shard d=128 (E/N = 14.5: the 512-B rows dominate, the
+  // step is HBM-gather-bound either way) 139 -> 152 ms, so that shape keeps the unfused passes.
+  if (t.attn_rows < 0 && 180.0 * (double)n_edges <= 24.0 * (double)d * (double)(n_q + n_k)) return false;
+  return plan_r->info.max_row < n_q && plan_r->info.max_index < n_k && plan_c->info.max_row < n_k &&
+         plan_c->info.max_index < n_q;
+}
+
+template <bool COL>
+int launch_attn_rows(const char* tag, const graphop_plan* plan, i64 n_chunks, int F, const float* own,
+                     const float* xt, const float4* st4, float* out0, float* out1, hipStream_t st) {
+  if (n_chunks == 0) return GRAPHOP_OK;
+  ProfScope prof(tag, st, "k_attn_bwd_rows_f32");
+  const bool owned = plan->info.rows_sorted != 0;
+  GO_DISPATCH_LNV(F, {
+    constexpr int GPB = kFastBlock / L;
+    const i64 groups_wanted = (i64)tuning().n_cu * GPB * 8;
+    i64 cpg = n_chunks / (groups_wanted > 0 ? groups_wanted : 1);
+    cpg = cpg < 1 ? 1 : (cpg > 16 ? 16 : cpg);
+    const unsigned nb = (unsigned)ceil_div(ceil_div(n_chunks, cpg), GPB);
+    if (owned)
+      hipLaunchKernelGGL((k_attn_bwd_rows_f32<L, NV, COL, true>), dim3(nb), dim3(kFastBlock), 0, st,
+                         (const i64*)plan->row, (const i64*)plan->indptr, (const i64*)plan->indices, own, xt,
+                         st4, out0, out1, n_chunks, (int)cpg);
+    else
+      hipLaunchKernelGGL((k_attn_bwd_rows_f32<L, NV, COL, false>), dim3(nb), dim3(kFastBlock), 0, st,
+                         (const i64*)plan->row, (const i64*)plan->indptr, (const i64*)plan->indices, own, xt,
+                         st4, out0, out1, n_chunks, (int)cpg);
+  });
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
 
 struct FastWs {
   float* kv; float* qdo; float4* st4; size_t total;
@@ -146,7 +190,8 @@ int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, 
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
                                   /*dry_run=*/true, &af);
   if (fast < 0) return -fast;
-  if (fast == 1) *bytes_out = (int64_t)FastWs(nullptr, n_q, n_k, h * d).total;
+  if (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c))
+    *bytes_out = (int64_t)FastWs(nullptr, n_q, n_k, h * d).total;
   else *bytes_out = (int64_t)SlowWs(nullptr, 4, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
   return GRAPHOP_OK;
 }
@@ -159,7 +204,7 @@ int graphop_attention_backward_is_fused(int dtype, int64_t n_edges, int64_t n_q,
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
                                   /*dry_run=*/true, &af);
   if (fast < 0) return -fast;
-  *fused_out = fast;
+  *fused_out = (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c)) ? 1 : 0;
   return GRAPHOP_OK;
 }
 
@@ -219,7 +264,8 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
   AttnFast af;
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, pr, pc, st, /*dry_run=*/false, &af);
   if (fast < 0) return -fast;
-  if (fast == 1) {
+  const bool rows_path = fast != 1 && attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, pr, pc);
+  if (fast == 1 || rows_path) {
     const i64 F = d;   // h == 1
     FastWs ws((char*)workspace, n_q, n_k, F);
     GO_CHECK_ARG(workspace != nullptr && (size_t)workspace_bytes >= ws.total,
@@ -242,6 +288,13 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
                            (const float*)stats, ws.st4);
       });
       GO_LAUNCH_CHECK();
+    }
+    if (rows_path) {
+      GO_TRY(launch_attn_rows<false>("attn_rows_row", pr, n_row_chunks, (int)F, ws.qdo, ws.kv, ws.st4, (float*)dQ,
+                                     nullptr, st));
+      GO_TRY(launch_attn_rows<true>("attn_rows_col", pc, n_col_chunks, (int)F, ws.kv, ws.qdo, ws.st4, (float*)dK,
+                                    (float*)dV, st));
+      return GRAPHOP_OK;
     }
     GO_TRY(launch_attn_pass<false>("attn_bwd_row", af.r, (int)F, n_k, ws.qdo, ws.kv, ws.st4, (float*)dQ,
                                    nullptr, st));

@@ -42,6 +42,7 @@ struct Tuning {
   int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
   int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
   int attn_bpc;           // resident workgroups per CU of the fused kernels
+  int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int n_cu;
   Tuning() {
@@ -67,6 +68,7 @@ struct Tuning {
     attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
+    attn_rows = env_int("GRAPHOP_ATTN_ROWS", -1);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
     n_cu = 256;
     int dev = 0;

@@ -251,6 +251,124 @@ __global__ __launch_bounds__(kFastBlock, BPC) void k_attn_bwd_wown_f32(
   }
 }
 
+// ---- chunk-driver form of the two passes (no window structure) -------------------------------------
+// For graphs the window drivers do not take (rows too short for column windows, tables that fit the
+// L2, chunk layouts without sorted rows): one lane group walks a run of consecutive chunks like
+// k_spmm_f32, keeps the packed own row and the accumulators in registers while the row id does not
+// change, gathers the packed neighbour rows straight from the table (HBM / Infinity Cache / L2 as
+// the table size has it) and stores (OWNED: the row's chunks all lie inside this group's run) or
+// atomically adds the sums.  Same per-slot arithmetic as the strips; the dot products are reduced
+// slot by slot in the chunk drivers' order (group_sum), which is the order the forward's SDDMM
+// used on these graphs.
+template <int L, int NV, bool COL, bool OWNED>
+__global__ __launch_bounds__(kFastBlock) void k_attn_bwd_rows_f32(
+    const i64* __restrict__ row, const i64* __restrict__ indptr, const i64* __restrict__ indices,
+    const float* __restrict__ OWN, const float* __restrict__ XT, const float4* __restrict__ stats4,
+    float* __restrict__ out0, float* __restrict__ out1, i64 n_chunks, int chunks_per_group) {
+  constexpr int SB = AttnCfg<L, NV>::SB;
+  constexpr i64 F4 = (i64)L * NV;
+  const int l = threadIdx.x % L;
+  const i64 gid = (i64)blockIdx.x * GroupCfg<L>::kGroupsPerBlock + threadIdx.x / L;
+  const i64 c0 = gid * chunks_per_group;
+  i64 c1 = c0 + chunks_per_group;
+  if (c1 > n_chunks) c1 = n_chunks;
+  if (c0 >= c1) return;
+  i64 row_before = -1, row_after = -1;
+  if constexpr (OWNED) {
+    if (c0 > 0) row_before = row[c0 - 1];
+    if (c1 < n_chunks) row_after = row[c1];
+  }
+  float4 y0[NV], y1[NV], acc0[NV], acc1[COL ? NV : 1];
+  float4 own_st = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc0[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < (COL ? NV : 1); ++v) acc1[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto flush = [&](i64 r) {
+    if (OWNED && r != row_before && r != row_after) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        reinterpret_cast<float4*>(out0)[r * F4 + v * L + l] = acc0[v];
+        if constexpr (COL) reinterpret_cast<float4*>(out1)[r * F4 + v * L + l] = acc1[v];
+      }
+    } else {
+      atomic_flush<L, NV>(out0, r, acc0, l);
+      if constexpr (COL) atomic_flush<L, NV>(out1, r, acc1, l);
+    }
+  };
+  zero_acc();
+  i64 cur_row = -1;
+  bool dirty = false;
+  for (i64 c = c0; c < c1; ++c) {
+    const i64 r = row[c];
+    if (r != cur_row) {
+      if (dirty) { flush(cur_row); zero_acc(); dirty = false; }
+      cur_row = r;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        y0[v] = ld4(OWN, r * 2 * F4 + v * L + l);
+        y1[v] = ld4(OWN, r * 2 * F4 + F4 + v * L + l);
+      }
+      if constexpr (!COL) own_st = stats4[r];
+    }
+    const i64 j0 = indptr[c], j1 = indptr[c + 1];
+    if (j1 > j0) dirty = true;
+    for (i64 jb = j0; jb < j1; jb += SB) {
+      const int nb = (j1 - jb) < SB ? (int)(j1 - jb) : SB;
+      // slots past the end re-read the batch's last neighbour with weights 0
+      i64 my_src = 0;
+      float4 st = own_st;
+      if (l < SB) {
+        my_src = indices[jb + (l < nb ? l : nb - 1)];
+        if constexpr (COL) st = stats4[my_src];
+      }
+      float4 x0[SB][NV], x1[SB][NV];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const i64 src = __shfl(my_src, u, L);
+        const float4* rowp = reinterpret_cast<const float4*>(XT) + src * (2 * F4) + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { x0[u][v] = rowp[v * L]; x1[u][v] = rowp[F4 + v * L]; }
+      }
+      float my_s = 0.f, my_da = 0.f;
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        float p = dot4(y0[0], x0[u][0]), q = dot4(y1[0], x1[u][0]);
+#pragma unroll
+        for (int v = 1; v < NV; ++v) { p += dot4(y0[v], x0[u][v]); q += dot4(y1[v], x1[u][v]); }
+        p = group_sum<L>(p);
+        q = group_sum<L>(q);
+        if (l == u) { my_s = p; my_da = q; }
+      }
+      float a_l = 0.f, ds_l = 0.f;
+      if (l < nb) {
+        a_l = expf(my_s - st.x) * st.y;
+        ds_l = a_l * (my_da - st.z);
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const float dsu = __shfl(ds_l, u, L);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          acc0[v].x = fmaf(dsu, x0[u][v].x, acc0[v].x); acc0[v].y = fmaf(dsu, x0[u][v].y, acc0[v].y);
+          acc0[v].z = fmaf(dsu, x0[u][v].z, acc0[v].z); acc0[v].w = fmaf(dsu, x0[u][v].w, acc0[v].w);
+        }
+        if constexpr (COL) {
+          const float au = __shfl(a_l, u, L);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            acc1[v].x = fmaf(au, x1[u][v].x, acc1[v].x); acc1[v].y = fmaf(au, x1[u][v].y, acc1[v].y);
+            acc1[v].z = fmaf(au, x1[u][v].z, acc1[v].z); acc1[v].w = fmaf(au, x1[u][v].w, acc1[v].w);
+          }
+        }
+      }
+    }
+  }
+  if (dirty) flush(cur_row);
+}
+
 // Row statistics of the general (plan-less) softmax path: its scratch holds max / sum per row.
 template <typename T>
 __global__ void k_attn_stats_from_ws(const T* __restrict__ max_val, const T* __restrict__ sum,

@@ -288,13 +288,15 @@ GRAPHOP_API int graphop_node_mul_edge_backward(int dtype, const int64_t* row, co
  *             (a = exp(s - m) / sum, ds = a (<dO_r, V_j> - <dO_r, o_r>)).
  * Results equal the composition of the unfused entry points up to fp32 summation order.
  * workspace: device scratch of graphop_attention_workspace_bytes(...) bytes (forward: s and a;
- * backward: packed operand tables when the fused window kernels apply -- fp32, h == 1, plans with
- * sorted rows, tables beyond the L2 -- else s, a, da, ds of the composed path). */
+ * backward: packed operand tables when the fused passes apply -- fp32, h == 1, both plans given;
+ * window-owner drivers for sweepable plans and tables beyond the L2, chunk drivers otherwise --
+ * else s, a, da, ds of the composed path). */
 GRAPHOP_API int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, int64_t n_q,
                                       int64_t n_k, int64_t h, int64_t d,
                                       const graphop_plan_t* plan_r, const graphop_plan_t* plan_c,
                                       void* stream, int64_t* bytes_out);
-/* 1 when graphop_attention_backward will run its fused window passes for these shapes / plans, 0 when
+/* 1 when graphop_attention_backward will run its fused passes (window-owner or chunk-driver form) for
+ * these shapes / plans, 0 when
  * it will compose the unfused entry points (and recompute s and a first): a caller that can keep a
  * from its forward (the Python autograd class does) then prefers the unfused backward ops. */
 GRAPHOP_API int graphop_attention_backward_is_fused(int dtype, int64_t n_edges, int64_t n_q, int64_t n_k, int64_t h,

@@ -42,6 +42,23 @@ def prof_tags(fn):
         _lib.profile_enable(False)
 
 
+def shuffled_chunk_arrays(g, seed):
+    """The graph's eight arrays with both chunk lists in random order (chunks of a row not adjacent)."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def shuffled(row, ptr):
+        perm = torch.randperm(row.numel(), generator=gen)
+        lens = (ptr[1:] - ptr[:-1])[perm]
+        new_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+        slot = torch.cat([torch.arange(int(ptr[c]), int(ptr[c + 1])) for c in perm.tolist()])
+        return row[perm].contiguous(), new_ptr, slot
+
+    row, ptr_r, sr = shuffled(g.row, g.ptr_r)
+    col, ptr_c, sc = shuffled(g.col, g.ptr_c)
+    return (row, ptr_r, g.eid_r[sr].contiguous(), g.indices_r[sr].contiguous(),
+            col, ptr_c, g.eid_c[sc].contiguous(), g.indices_c[sc].contiguous())
+
+
 @pytest.fixture
 def force_sweep():
     _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 4); _lib.tune("vrow_t", 64)
@@ -95,6 +112,48 @@ def test_fused_window_passes_vs_oracle(dev, force_sweep, d, scale, k, bpc):
         close(got[key], want[key])
     tags = prof_tags(lambda: fused_step(gd, *args))
     assert {"attn_bwd_row", "attn_bwd_col"} <= tags, tags          # the fused kernels did run
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 256, 1024])
+@pytest.mark.parametrize("chunk_size,rows_sorted", [(8, True), (32, True), (8, False)])
+def test_fused_chunk_driver_passes_vs_oracle(dev, d, chunk_size, rows_sorted):
+    """The chunk-driver form of the fused passes (graphs with no window structure): forced on at every
+    width; empty rows, a hub row cut into many chunks (the atomic merge), non-square; with the chunk
+    list shuffled the kernels cannot own rows and every row is merged by atomics."""
+    n = 64 if d >= 256 else 300
+    g = random_graph(n, n + 37, 9 * n, seed=3 + d, chunk_size=chunk_size, zero_rows=0.2, hub=n // 2)
+    inp = rand_inputs(g, 1, d, seed=4, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"][:g.n_src])
+    want["o"] = want["o"][:g.n_src]
+    a8 = g.csr_args() if rows_sorted else shuffled_chunk_arrays(g, seed=11)
+    a8 = tuple(v.to(dev) for v in a8)
+    Q, K, V = (inp[x].to(dev) for x in ("Q", "K", "V"))
+    dO = inp["dO"][:g.n_src].to(dev)
+
+    def step():
+        o, stats = ops.attention_forward(*a8[:4], Q, K, V)
+        return (o,) + tuple(ops.attention_backward(*a8, Q, K, V, o, stats, dO))
+
+    _lib.tune("attn_rows", 1); _lib.clear_plan_cache()
+    try:
+        assert ops.attention_backward_is_fused(*a8, Q, K)
+        got = dict(zip(("o", "dQ", "dK", "dV"), step()))
+        assert {"attn_rows_row", "attn_rows_col"} <= prof_tags(step)
+        for key in ("o", "dQ", "dK", "dV"):
+            close(got[key], want[key])
+        _lib.tune("attn_rows", 0); _lib.clear_plan_cache()
+        assert not ({"attn_rows_row", "attn_rows_col"} & prof_tags(step))
+    finally:
+        _lib.tune("attn_rows", -1); _lib.clear_plan_cache()
+
+
+def test_fused_chunk_driver_cost_rule(dev):
+    """Default knobs: the chunk-driver passes run where the avoided E-sized streams outweigh packing
+    (narrow rows, E/N large) and the composition runs where they do not (wide rows, E/N small)."""
+    g = random_graph(400, 400, 8000, seed=2, chunk_size=32).to(dev)
+    for d, want in ((16, True), (128, False)):
+        Q = torch.zeros(400, d, device=dev)
+        assert ops.attention_backward_is_fused(*g.csr_args(), Q, Q) == want, d
 
 
 def test_fused_matches_unfused_medium_powerlaw(dev):
@@ -164,19 +223,7 @@ def test_fused_unordered_chunks_take_the_general_path(dev, h, d):
     atomics path with scratch from the workspace, and the fused op must still match."""
     g = random_graph(150, 150, 5000, seed=11, chunk_size=8, hub=300)
     inp = rand_inputs(g, h, d, seed=6, normal=True)
-    gen = torch.Generator().manual_seed(0)
-
-    def shuffled(row, ptr):
-        perm = torch.randperm(row.numel(), generator=gen)
-        lens = (ptr[1:] - ptr[:-1])[perm]
-        new_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
-        slot = torch.cat([torch.arange(int(ptr[c]), int(ptr[c + 1])) for c in perm.tolist()])
-        return row[perm].contiguous(), new_ptr, slot
-
-    row, ptr_r, sr = shuffled(g.row, g.ptr_r)
-    col, ptr_c, sc = shuffled(g.col, g.ptr_c)
-    a8 = (row, ptr_r, g.eid_r[sr].contiguous(), g.indices_r[sr].contiguous(),
-          col, ptr_c, g.eid_c[sc].contiguous(), g.indices_c[sc].contiguous())
+    a8 = shuffled_chunk_arrays(g, seed=0)
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
     a8d = tuple(v.to(dev) for v in a8)
     assert _lib.get_plan(*a8d[:4], n_index_bound=g.n_dst).info.row_owned == 0

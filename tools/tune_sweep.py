@@ -43,7 +43,7 @@ def main():
              "sddmm_bwd_dA", "sddmm_bwd_dB"]
     step = functions.attention_step
     if args.fused:
-        order = ["sddmm_fwd", "softmax_fwd", "spmm_fwd", "attn_pack", "attn_bwd_row", "attn_bwd_col"]
+        order = ["sddmm_fwd", "softmax_fwd", "spmm_fwd", "attn_pack", "attn_bwd_row", "attn_bwd_col", "attn_rows_row", "attn_rows_col"]
         step = functions.fused_attention_step
     print("# N=%d E=%d h=%d d=%d ; columns: step-wall (sum of pass times) " % (N, E, args.heads, args.d) + " ".join(order), flush=True)
     for setting in args.settings:
