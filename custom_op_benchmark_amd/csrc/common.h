@@ -88,6 +88,21 @@ struct Sweep {
   int* sync = nullptr;    // [kSweepSyncInts] pacing counters (zeroed before every sweep launch)
   int* queues = nullptr;  // [kQueueRing][8 * 64] task-queue heads of the window-owner drivers
   unsigned queue_next = 0;  // next ring slot (taken under the plan's sweep mutex)
+  // Window-major ("dealt") layouts of the window-owner tasks, one per lane-group geometry, built on
+  // first use: the granules of every (window, vrow tile) task are dealt to the wave's lane groups
+  // once, here, and the neighbour ids of each group's strip are stored as ONE contiguous,
+  // 16-byte-aligned run, so a strip fetches its ids with a few wide loads (kernels_fast.h, staged strips).
+  struct Dealt {
+    int L = 0, K = 0;       // lanes per group, vrows per group: tile = (64 / L) * K vrows per task
+    int tiles = 0;          // tasks per window
+    int* rec = nullptr;     // int4 [W * tiles * tile]: (first slot, length, row id, position in ids) per granule, dealt order
+    int* ids = nullptr;     // neighbour ids, window-major dealt order (strips padded to 4 ints)
+    int* eids = nullptr;    // same order: edge ids (nullptr when eid is the identity)
+    long long n_ids = 0;
+  };
+  static constexpr int kMaxDealt = 4;
+  Dealt dealt[kMaxDealt];
+  int n_dealt = 0;
 };
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)

@@ -103,6 +103,7 @@ int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_
 int plan_build(graphop_plan*, i64, hipStream_t, int);
 int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
 int* plan_take_queue(graphop_plan*, const Sweep*);
+int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
@@ -257,6 +258,17 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
     if (nb > need) nb = need;
     out->blocks = (unsigned)(nb < 1 ? 1 : nb);
     out->lds_bytes = (size_t)gpb * K * row_bytes;
+    if (opts && opts->staged) {
+      const Sweep::Dealt* dl = nullptr;
+      const int rcd = plan_get_dealt(const_cast<graphop_plan*>(plan), sw, L, K, st, &dl);
+      if (rcd != GRAPHOP_OK) return -rcd;
+      if (dl) {
+        out->view.rec = (const int4*)dl->rec;
+        out->view.ids_w = dl->ids;
+        out->view.eids_w = dl->eids;
+        out->lds_bytes += (size_t)gpb * opts->stage_lds_per_group;
+      }
+    }
     return 1;
   }
   // grid: a multiple of 8 workgroups; XCD slot x (= blockIdx % 8) owns vrows [x*vx, (x+1)*vx)
@@ -304,15 +316,22 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   SweepOpts so;
   so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
   so.touch = tuning().touch_sddmm;
+  const bool id = plan->info.eid_identity != 0;
+  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);   // table < 4 GiB: 32-bit byte offsets
+  so.staged = (tuning().staged_ids & 1) && h == 1 && id && off32;
+  so.stage_lds_per_group = StageCfg<L>::SEG * (int)sizeof(int);
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
   if (use != 1) return use;
-  ProfScope prof(tag, st, sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
-  const bool id = plan->info.eid_identity != 0;
+  const bool staged = sl.window_owner && sl.view.rec != nullptr;
+  ProfScope prof(tag, st, staged ? "k_sddmm_wown_staged_f32" : sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
   const float* a = (const float*)A;
   const float* b = (const float*)B;
   float* yy = (float*)y;
-  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);   // table < 4 GiB: 32-bit byte offsets
+  if (staged) {
+    hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+    return 1;
+  }
 #define GO_K(H1, ID, O32)                                                                          \
   do {                                                                                             \
     if (sl.window_owner)                                                                           \
@@ -746,7 +765,7 @@ int graphop_tune(const char* key, int value) {
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
-      {"attn_rows", &t.attn_rows},
+      {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids},
       {"touch_sddmm", &t.touch_sddmm}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {

@@ -42,6 +42,8 @@ struct Tuning {
   int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
   int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
   int attn_bpc;           // resident workgroups per CU of the fused kernels
+  int staged_ids;         // window-owner SDDMM: plan-time deal + contiguous ids staged through LDS (measured: no gain on
+                          // the real passes, 1.80 vs 1.74 ms, although the all-L2-hit model gains 29 %; off, kept as a knob)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int n_cu;
@@ -69,6 +71,7 @@ struct Tuning {
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
     attn_rows = env_int("GRAPHOP_ATTN_ROWS", -1);
+    staged_ids = env_int("GRAPHOP_STAGED_IDS", 0);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
     n_cu = 256;
     int dev = 0;
@@ -113,6 +116,8 @@ struct SweepOpts {
   int require_owner = 0;  // 1: only the window-owner order is acceptable (return 0 otherwise)
   int dry_run = 0;        // 1: decide and build the cached structure only (no task queue is taken)
   int touch = 0;          // SweepView::touch of the launch
+  int staged = 0;         // 1: also fetch / build the dealt (window-major) layout and put it in the view
+  int stage_lds_per_group = 0;   // bytes of LDS each lane group needs for staging (added to lds_bytes)
 };
 
 // Decide whether the window-sweep driver applies and fetch / build its structure.

@@ -238,6 +238,88 @@ __global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restri
   }
 }
 
+// ---- dealt (window-major) task layout ---------------------------------------------------------------
+// One wave per (window w, tile t).  Same deal as the run-time one (kernels_fast.h, WownTask::load):
+// rank the tile's granules by length (longest first, ties by lane) and hand them to the wave's GW
+// lane groups in snake order; record (g, k) = (first slot, length, row id, 0) at
+// rec[((w * tiles + t) * tile + g * K + k)] and the group's total, rounded up to 4, at strip_len.
+__global__ __launch_bounds__(256) void k_deal_records(const int* __restrict__ wp_lo,
+                                                      const int* __restrict__ wp_hi,
+                                                      const int* __restrict__ vr_row, int V, int W,
+                                                      int L, int K, int tiles, int4* __restrict__ rec,
+                                                      int* __restrict__ strip_len) {
+  const int GW = 64 / L, tile = GW * K;
+  const int lane = threadIdx.x & 63;
+  const i64 task = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (task >= (i64)W * tiles) return;
+  const int w = (int)(task / tiles), t = (int)(task % tiles);
+  const i64 v = (i64)t * tile + lane;
+  int lo_s = 0, hi_s = 0, row_s = 0;
+  if (lane < tile && v < V) {
+    lo_s = wp_lo[(i64)w * V + v];
+    hi_s = wp_hi[(i64)w * V + v];
+    row_s = vr_row[v];
+  }
+  int lo_d = lo_s, hi_d = hi_s, row_d = row_s;
+  const int g = lane / L, k = lane % L;
+  if (GW > 1) {
+    const int len = hi_s - lo_s;
+    int rank = 0;
+    for (int j = 0; j < tile; ++j) {
+      const int lj = __shfl(len, j);
+      rank += (lj > len || (lj == len && j < lane)) ? 1 : 0;
+    }
+    if (lane >= tile) rank = lane;
+    const int inv = __builtin_amdgcn_ds_permute(rank << 2, lane);
+    const int r = k * GW + ((k & 1) ? GW - 1 - g : g);
+    const int src = __shfl(inv, r < tile ? r : 0);
+    lo_d = __shfl(lo_s, src); hi_d = __shfl(hi_s, src); row_d = __shfl(row_s, src);
+  }
+  const bool mine = k < K;
+  int n = mine ? hi_d - lo_d : 0;
+  if (mine) rec[task * tile + g * K + k] = make_int4(lo_d, n, row_d, 0);
+  for (int off = 1; off < L; off <<= 1) n += __shfl_xor(n, off, L);
+  if (k == 0) strip_len[task * GW + g] = (n + 3) & ~3;
+}
+
+// Second pass: positions (exclusive prefix inside the strip on top of the strip's scanned start)
+// and the id copies.
+__global__ __launch_bounds__(256) void k_deal_fill(const int* __restrict__ strip_pos, int W, int L, int K,
+                                                   int tiles, const int32_t* __restrict__ idx32,
+                                                   const int32_t* __restrict__ eid32,
+                                                   int4* __restrict__ rec, int* __restrict__ ids,
+                                                   int* __restrict__ eids) {
+  const int GW = 64 / L, tile = GW * K;
+  const int lane = threadIdx.x & 63;
+  const i64 task = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (task >= (i64)W * tiles) return;
+  const int g = lane / L, k = lane % L;
+  const bool mine = k < K;
+  int4 r = make_int4(0, 0, 0, 0);
+  if (mine) r = rec[task * tile + g * K + k];
+  int P = r.y;
+  for (int off = 1; off < L; off <<= 1) {
+    const int up = __shfl_up(P, off, L);
+    if (k >= off) P += up;
+  }
+  const int base = strip_pos[task * GW + g];
+  const int pos = base + P - r.y;
+  if (mine) { r.w = pos; rec[task * tile + g * K + k] = r; }
+  const int total = __shfl(P, L - 1, L);
+  for (int kk = 0; kk < K; ++kk) {
+    const int lo = __shfl(r.x, kk, L), n = __shfl(r.y, kk, L), at = __shfl(pos, kk, L);
+    for (int i = k; i < n; i += L) {
+      ids[at + i] = idx32[lo + i];
+      if (eids) eids[at + i] = eid32[lo + i];
+    }
+  }
+  // padding up to the next multiple of 4: a valid id (0), never used
+  for (int i = total + k; i < ((total + 3) & ~3); i += L) {
+    ids[base + i] = 0;
+    if (eids) eids[base + i] = 0;
+  }
+}
+
 // ---- block-dense cover -----------------------------------------------------------------------------
 // same[s] = 1 when segment s has the same neighbour list (length and ids, in order) as segment
 // s - 1; also fills the 32-bit segment tables the block kernels read.
@@ -574,12 +656,65 @@ int* plan_take_queue(graphop_plan* p, const Sweep* sw) {
   return s->queues + (size_t)(s->queue_next++ % kQueueRing) * kQueueInts;
 }
 
+// The dealt layout of `sw` for groups of L lanes with K vrows each (built once, kept with the sweep).
+int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t st, const Sweep::Dealt** out) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  Sweep* s = const_cast<Sweep*>(sw);
+  for (int i = 0; i < s->n_dealt; ++i)
+    if (s->dealt[i].L == L && s->dealt[i].K == K) { *out = &s->dealt[i]; return GRAPHOP_OK; }
+  *out = nullptr;
+  if (s->n_dealt >= Sweep::kMaxDealt) return GRAPHOP_OK;   // caller falls back to the plain strips
+  {
+    const int rc_cap = check_not_capturing(st, "building the window-major id layout of a plan");
+    if (rc_cap != GRAPHOP_OK) return rc_cap;
+  }
+  GO_CHECK_ARG(L >= 1 && L <= 64 && (64 % L) == 0 && K >= 1 && K <= L, "plan_get_dealt: bad geometry");
+  const int GW = 64 / L, tile = GW * K;
+  const i64 tiles = ceil_div((i64)s->V, tile);
+  const i64 tasks = tiles * s->W, strips = tasks * GW;
+  const i64 E = p->info.n_edges;
+  if (tasks * tile >= 0x7fffffffLL || E + 4 * strips + 64 >= 0x7fffffffLL) return GRAPHOP_OK;
+  Sweep::Dealt d;
+  d.L = L; d.K = K; d.tiles = (int)tiles;
+  d.n_ids = E + 3 * strips + 64;   // upper bound: every strip padded to 4 ints, slack for the last wide load
+  DevBuf len, tmp;
+  GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(strips + 1), st));
+  const bool with_eid = !p->info.eid_identity && p->eid32;
+  if (go_malloc((void**)&d.rec, sizeof(int4) * (size_t)(tasks * tile), st) != hipSuccess ||
+      go_malloc((void**)&d.ids, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess ||
+      (with_eid && go_malloc((void**)&d.eids, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess)) {
+    go_free(d.rec); go_free(d.ids); go_free(d.eids);
+    set_error("plan_get_dealt: out of device memory for %lld ids", (long long)d.n_ids);
+    return GRAPHOP_ERR_HIP;
+  }
+  auto fail = [&](int rc) { go_free(d.rec); go_free(d.ids); go_free(d.eids); return rc; };
+  const unsigned grid = (unsigned)ceil_div(tasks, 4);
+  hipLaunchKernelGGL(k_deal_records, dim3(grid), dim3(256), 0, st, s->wp_lo, s->wp_hi, s->vr_row, s->V, s->W,
+                     L, K, (int)tiles, (int4*)d.rec, (int*)len.p);
+  if (hipGetLastError() != hipSuccess) return fail(GRAPHOP_ERR_HIP);
+  size_t tmp_bytes = 0;
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)len.p, (int*)len.p, (int)(strips + 1), st) != hipSuccess ||
+      go_malloc(&tmp.p, tmp_bytes, st) != hipSuccess ||
+      hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (int*)len.p, (int*)len.p, (int)(strips + 1), st) != hipSuccess)
+    return fail(GRAPHOP_ERR_HIP);
+  if (hipMemsetAsync(d.ids, 0, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
+  if (d.eids && hipMemsetAsync(d.eids, 0, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
+  hipLaunchKernelGGL(k_deal_fill, dim3(grid), dim3(256), 0, st, (const int*)len.p, s->W, L, K, (int)tiles,
+                     (const int32_t*)p->idx32, (const int32_t*)(with_eid ? p->eid32 : nullptr), (int4*)d.rec,
+                     d.ids, d.eids);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
+  s->dealt[s->n_dealt] = d;
+  *out = &s->dealt[s->n_dealt++];
+  return GRAPHOP_OK;
+}
+
 void plan_free_sweeps(graphop_plan* p) {
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
     for (auto& s : *vec) {
       go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync);
       go_free(s.queues);
+      for (int i = 0; i < s.n_dealt; ++i) { go_free(s.dealt[i].rec); go_free(s.dealt[i].ids); go_free(s.dealt[i].eids); }
     }
     delete vec;
   }

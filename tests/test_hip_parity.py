@@ -391,6 +391,32 @@ def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d, mode):
         close(got[k], want[k])
 
 
+@pytest.mark.parametrize("d", [16, 32, 64, 256, 1024])
+def test_staged_id_strips_vs_oracle(dev, force_sweep, d):
+    """Window-owner SDDMM with the plan-time deal and ids staged through LDS (knob staged_ids, off by
+    default): same graph as above; strips longer than one 128-slot segment, empty granules, the
+    padded tail of a strip."""
+    _lib.tune("staged_ids", 1); _lib.tune("sweep_bpc", 1 if d <= 64 else 4); _lib.clear_plan_cache()
+    try:
+        n = 120 if d >= 512 else 1500
+        g = random_graph(n, n + 41, 10 * n, seed=77 + d, chunk_size=32, zero_rows=0.15, hub=900)
+        inp = rand_inputs(g, 1, d, seed=8, normal=True)
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+        gd = g.to(dev)
+        args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+        got = hip_step(gd, *args)
+        for k in ("s", "a", "o", "dQ", "dK", "dV"):
+            close(got[k], want[k])
+        _lib.profile_enable(True)
+        hip_step(gd, *args)
+        torch.cuda.synchronize()
+        kernels = {r.get("kernel") for r in _lib.profile_read().values()}
+        _lib.profile_enable(False)
+        assert "k_sddmm_wown_staged_f32" in kernels, kernels
+    finally:
+        _lib.tune("staged_ids", 0); _lib.clear_plan_cache()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
     """Same inputs through both drivers: equal within fp32 re-association."""

@@ -65,6 +65,64 @@ __global__ __launch_bounds__(256, 4) void k_model(const float4* __restrict__ tab
   if (acc.x + acc.y + acc.z + acc.w + res == 1234.5f) out[0] = acc.x;
 }
 
+// Staged ids: a group fetches the ids of a whole task (TB batches) with dwordx4 loads one task
+// ahead, parks them in LDS at the task switch and reads one id per lane and batch with ds_read --
+// between two batches of row requests the vector memory pipeline sees no other load.
+template <int MODE, int TB>
+__global__ __launch_bounds__(256, 4) void k_model_staged(const float4* __restrict__ table, unsigned n_rows,
+                                                         const int* __restrict__ ids, long n_edges,
+                                                         float* __restrict__ y, float* __restrict__ out) {
+  __shared__ float4 rows[16 * 4 * 16];
+  __shared__ int idbuf[16][TB * 16];
+  const int l = threadIdx.x & 15, g = threadIdx.x >> 4;
+  for (int i = threadIdx.x; i < 16 * 4 * 16; i += 256) rows[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  __syncthreads();
+  const long n_groups = (long)gridDim.x * 16;
+  const long gid = (long)blockIdx.x * 16 + g;
+  long per = (n_edges + n_groups - 1) / n_groups;
+  per = (per + TB * 16 - 1) / (TB * 16) * (TB * 16);
+  const long e0 = gid * per, e1 = e0 + per < n_edges ? e0 + per : n_edges;
+  float res = 0.f;
+  float4 acc = make_float4(0, 0, 0, 0);
+  constexpr int NQ = TB / 4;
+  int4 nx[NQ];
+  auto fetch = [&](long base) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const long at = base + k * 64 + l * 4;
+      nx[k] = (at + 3 < e1) ? *reinterpret_cast<const int4*>(ids + at) : make_int4(0, 0, 0, 0);
+    }
+  };
+  if (e0 < e1) fetch(e0);
+  for (long base = e0; base < e1; base += TB * 16) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) *reinterpret_cast<int4*>(&idbuf[g][k * 64 + l * 4]) = nx[k];
+    fetch(base + TB * 16);
+    for (int bt = 0; bt < TB; ++bt) {
+      const long jb = base + bt * 16;
+      if (jb >= e1) break;
+      const int my = idbuf[g][bt * 16 + l];
+      float4 b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int row = __shfl(my, u, 16);
+        b[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + ((unsigned)row * 256u + l * 16u));
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (MODE >= 2) {
+          const float4 a = rows[(g * 4 + (u & 3)) * 16 + l];
+          float p = a.x * b[u].x + a.y * b[u].y + a.z * b[u].z + a.w * b[u].w;
+          p = sum16(p);
+          if (l == u) res = p;
+        } else { acc.x += b[u].x; acc.y += b[u].y; acc.z += b[u].z; acc.w += b[u].w; }
+      }
+      if (MODE >= 3) { if (jb + l < e1) __builtin_nontemporal_store(res, y + jb + l); }
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w + res == 1234.5f) out[0] = acc.x;
+}
+
 int main() {
   const long E = 114615892;
   const unsigned n_rows = 3700u * 1024 / 256;
@@ -76,7 +134,7 @@ int main() {
   for (long i = 0; i < E; ++i) { r = r * 1664525u + 1013904223u; h[i] = (int)((r >> 4) % n_rows); }
   CK(hipMemcpy(ids, h.data(), E * 4, hipMemcpyHostToDevice));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int mode = 0; mode < 8; ++mode) {
+  for (int mode = 0; mode < 14; ++mode) {
     auto launch = [&]() {
       switch (mode) {
         case 0: hipLaunchKernelGGL((k_model<0, 0>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
@@ -86,7 +144,13 @@ int main() {
         case 4: hipLaunchKernelGGL((k_model<3, 1>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
         case 5: hipLaunchKernelGGL((k_model<3, 2>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
         case 6: hipLaunchKernelGGL((k_model<3, 3>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
-        default: hipLaunchKernelGGL((k_model<3, 4>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 7: hipLaunchKernelGGL((k_model<3, 4>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 8: hipLaunchKernelGGL((k_model_staged<1, 8>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 9: hipLaunchKernelGGL((k_model_staged<1, 16>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 10: hipLaunchKernelGGL((k_model_staged<2, 16>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 11: hipLaunchKernelGGL((k_model_staged<3, 8>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        case 12: hipLaunchKernelGGL((k_model_staged<3, 16>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
+        default: hipLaunchKernelGGL((k_model_staged<3, 32>), dim3(1024), dim3(256), 0, 0, table, n_rows, ids, E, y, out); break;
       }
     };
     launch(); launch();
@@ -94,8 +158,11 @@ int main() {
     for (int i = 0; i < 5; ++i) launch();
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 5;
-    printf("mode %d%s : %.3f ms  (row gather %.1f TB/s)\n", mode < 4 ? mode : 3,
-           mode < 4 ? "" : (mode == 4 ? " + ids 1 batch ahead" : mode == 5 ? " + ids 2 ahead" : mode == 6 ? " + ids 3 ahead" : " + ids 4 ahead"),
+    static const char* names[14] = {"", "", "", "", " + ids 1 batch ahead", " + ids 2 ahead", " + ids 3 ahead", " + ids 4 ahead",
+                                    " ids staged in LDS per 8 batches (mode 1 work)", " ids staged per 16 batches (mode 1 work)",
+                                    " ids staged per 16 batches (mode 2 work)", " ids staged per 8 batches", " ids staged per 16 batches",
+                                    " ids staged per 32 batches"};
+    printf("mode %d%s : %.3f ms  (row gather %.1f TB/s)\n", mode < 4 ? mode : (mode < 8 || mode > 10 ? 3 : (mode == 10 ? 2 : 1)), names[mode],
            ms, (double)E * 256 / ms / 1e9);
   }
   return 0;
