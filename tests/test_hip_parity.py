@@ -396,7 +396,8 @@ def test_staged_id_strips_vs_oracle(dev, force_sweep, d):
     """Window-owner SDDMM with the plan-time deal and ids staged through LDS (knob staged_ids, off by
     default): same graph as above; strips longer than one 128-slot segment, empty granules, the
     padded tail of a strip."""
-    _lib.tune("staged_ids", 1); _lib.tune("sweep_bpc", 1 if d <= 64 else 4); _lib.clear_plan_cache()
+    _lib.tune("staged_ids", 1); _lib.tune("sweep_bpc", 1 if d <= 64 else 4)
+    _lib.tune("window_kb", 4 * max(1, d // 64)); _lib.clear_plan_cache()      # a few rows per window at every width
     try:
         n = 120 if d >= 512 else 1500
         g = random_graph(n, n + 41, 10 * n, seed=77 + d, chunk_size=32, zero_rows=0.15, hub=900)
