@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -34,7 +34,7 @@ class PlanInfo(ctypes.Structure):
 
 class SweepInfo(ctypes.Structure):
     _fields_ = [("win_cols", _c64), ("W", ctypes.c_int32), ("T", ctypes.c_int32), ("V", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("n_dealt", ctypes.c_int32)]
 
 
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
@@ -63,6 +63,8 @@ _SIGNATURES = {
     "graphop_plan_array": [_P, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_c64)],
     "graphop_plan_import": [_P] * 4 + [ctypes.POINTER(PlanInfo)] + [_P] * 4 + [_c64] + [_P] * 4 + [ctypes.POINTER(_vp)],
     "graphop_plan_import_sweep": [_P, ctypes.POINTER(SweepInfo), _P, _P, _P, _P],
+    "graphop_plan_sweep_dealt": [_P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)],
+    "graphop_plan_sweep_build_dealt": [_P, ctypes.POINTER(SweepInfo), ctypes.c_int32, ctypes.c_int32, _P],
     "graphop_maskedmm_csr_forward": [ctypes.c_int] + [_P] * 7 + [_c64] * 6 + [_P, _P],
     "graphop_maskedmm_csr_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_sparse_softmax_forward": [ctypes.c_int] + [_P] * 5 + [_c64] * 3 + [_P, _c64, _P, _P],
@@ -242,9 +244,13 @@ class Plan:
         for i in range(lib().graphop_plan_n_sweeps(self.handle)):
             si = SweepInfo()
             check(lib().graphop_plan_sweep_info(self.handle, i, ctypes.byref(si)))
-            sw = {"W": si.W, "T": si.T, "V": si.V, "win_cols": si.win_cols}
+            sw = {"W": si.W, "T": si.T, "V": si.V, "win_cols": si.win_cols, "dealt": []}
             for name in _SWEEP_ARRAYS:
                 sw[name] = self._array(name, torch.int32, i)
+            for j in range(si.n_dealt):      # window-major id layouts: only their geometry travels
+                L, K = ctypes.c_int32(0), ctypes.c_int32(0)
+                check(lib().graphop_plan_sweep_dealt(self.handle, i, j, ctypes.byref(L), ctypes.byref(K)))
+                sw["dealt"].append((int(L.value), int(K.value)))
             st["sweeps"].append(sw)
         return st
 
@@ -259,10 +265,12 @@ class Plan:
                                         ptr(arrs["long_segs"]), n_long, ptr(arrs["blk_seg"]), ptr(arrs["seg_e0"]),
                                         ptr(arrs["seg_row"]), stream_of(indptr), ctypes.byref(handle)))
         for sw in state.get("sweeps", []):
-            si = SweepInfo(win_cols=sw["win_cols"], W=sw["W"], T=sw["T"], V=sw["V"], reserved=0)
+            si = SweepInfo(win_cols=sw["win_cols"], W=sw["W"], T=sw["T"], V=sw["V"], n_dealt=0)
             a = [sw[name].to(dev) for name in _SWEEP_ARRAYS]
             check(lib().graphop_plan_import_sweep(handle, ctypes.byref(si), ptr(a[0]), ptr(a[1]), ptr(a[2]),
                                                   stream_of(indptr)))
+            for L, K in sw.get("dealt", []):
+                check(lib().graphop_plan_sweep_build_dealt(handle, ctypes.byref(si), L, K, stream_of(indptr)))
         torch.cuda.current_stream(dev).synchronize()     # the staging tensors die here
         return handle
 

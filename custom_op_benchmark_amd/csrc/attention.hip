@@ -17,6 +17,9 @@ namespace {
 // resident workgroups per CU the fused kernels are compiled for: the column-major pass carries two
 // accumulators and the statistics pipeline and needs more than 128 VGPRs; so do rows of >= 512 floats
 constexpr int attn_bpc(int NV, bool col) { return col ? (NV >= 4 ? 2 : 3) : (NV >= 2 ? 3 : 4); }
+// with the ids staged through LDS (4 more VGPRs, 1 KB more LDS per group) the one-row pass runs 3 per CU
+constexpr int attn_bpc_staged(int NV, bool col) { return col ? (NV >= 4 ? 2 : 3) : 3; }
+inline bool attn_staged(int L, int NV) { return (tuning().staged_ids & 4) && L == 16 && NV == 1; }   // d = 64: the other widths would spill in the column pass
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -32,7 +35,9 @@ SweepOpts attn_opts(int L, int NV, bool col, bool dry_run) {
   o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
   o.require_owner = 1;
   o.dry_run = dry_run ? 1 : 0;
-  const int cap = attn_bpc(NV, col);
+  o.staged = attn_staged(L, NV) ? 1 : 0;
+  o.stage_lds_per_group = (4 * L > 128 ? 4 * L : 128) * 2 * (int)sizeof(int);   // StageCfg<L, 1>::kLdsIntsPerGroup ints
+  const int cap = o.staged ? attn_bpc_staged(NV, col) : attn_bpc(NV, col);
   o.bpc = (t.attn_bpc > 0 && t.attn_bpc < cap) ? t.attn_bpc : cap;
   return o;
 }
@@ -143,7 +148,21 @@ int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gather
   GO_DISPATCH_LNV(F, {
     const bool off32 = n_gathered * 2 * 16LL * L * NV < (1LL << 32);
     constexpr int BPC = attn_bpc(NV, COL);
-    if (off32)
+    bool staged = false;
+    if constexpr (L == 16 && NV == 1) {
+      if (sl.view.rec != nullptr) {
+        constexpr int BPS = attn_bpc_staged(NV, COL);
+        staged = true;
+        if (off32)
+          hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, true, BPS, true>), grid, block, sl.lds_bytes, st,
+                             sl.view, own, xt, st4, out0, out1);
+        else
+          hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, false, BPS, true>), grid, block, sl.lds_bytes, st,
+                             sl.view, own, xt, st4, out0, out1);
+      }
+    }
+    if (staged) {
+    } else if (off32)
       hipLaunchKernelGGL((k_attn_bwd_wown_f32<L, NV, COL, true, BPC>), grid, block, sl.lds_bytes, st,
                          sl.view, own, xt, st4, out0, out1);
     else

@@ -309,6 +309,15 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
 
 namespace {
 
+// Which window-owner passes take the dealt layout + staged ids (also what graphop_plan_prepare builds).
+inline bool table_off32(i64 n_table_rows, int L, int NV) { return n_table_rows * 16LL * L * NV < (1LL << 32); }
+inline bool sddmm_staged(const graphop_plan* plan, int L, int NV, i64 h, i64 n_table_rows) {
+  return (tuning().staged_ids & 1) && h == 1 && plan->info.eid_identity && table_off32(n_table_rows, L, NV);
+}
+inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {   // 64-lane groups (d >= 256) would spill with the staging registers
+  return L <= 32 && (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
+}
+
 template <int L, int NV>
 int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
                     const void* B, void* y, i64 h, int d4, hipStream_t st) {
@@ -317,9 +326,9 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
   so.touch = tuning().touch_sddmm;
   const bool id = plan->info.eid_identity != 0;
-  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);   // table < 4 GiB: 32-bit byte offsets
-  so.staged = (tuning().staged_ids & 1) && h == 1 && id && off32;
-  so.stage_lds_per_group = StageCfg<L>::SEG * (int)sizeof(int);
+  const bool off32 = table_off32(n_table_rows, L, NV);   // table < 4 GiB: 32-bit byte offsets
+  so.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
+  so.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int);
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
   if (use != 1) return use;
   const bool staged = sl.window_owner && sl.view.rec != nullptr;
@@ -386,6 +395,9 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   SweepLaunch sl;
   SweepOpts so;
   so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  const bool off32 = table_off32(n_table_rows, L, NV);
+  constexpr bool kStagedOk = L <= 32;
+  so.staged = spmm_staged(L, NV, h, n_table_rows);
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &so);
   if (use != 1) return use;
   bool id = plan->info.eid_identity != 0;
@@ -396,11 +408,19 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
     if (tr < 0) return tr;
     if (tr == 1) { ww = w_slot; id = true; }
   }
-  ProfScope prof(tag, st, sl.window_owner ? "k_spmm_wown_f32" : "k_spmm_sweep_f32");
+  const bool staged = sl.window_owner && sl.view.rec != nullptr && (id || sl.view.eids_w != nullptr);
+  ProfScope prof(tag, st, staged ? "k_spmm_wown_staged_f32" : sl.window_owner ? "k_spmm_wown_f32" : "k_spmm_sweep_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
   const float* x = (const float*)X;
   float* o = (float*)out;
-  const bool off32 = n_table_rows * 16LL * L * NV < (1LL << 32);
+  if constexpr (kStagedOk) {
+    if (staged) {
+      const size_t lds = (size_t)(kFastBlock / L) * (id ? StageCfg<L, 1>::kLdsIntsPerGroup : StageCfg<L, 2>::kLdsIntsPerGroup) * sizeof(int);
+      if (id) hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, true>), grid, block, lds, st, sl.view, ww, x, o);
+      else hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, false>), grid, block, lds, st, sl.view, ww, x, o);
+      return 1;
+    }
+  }
 #define GO_K(H1, ID, O32)                                                                          \
   do {                                                                                             \
     if (sl.window_owner)                                                                           \
@@ -890,7 +910,10 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
     SweepOpts o;
     o.dry_run = 1;
     o.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+    o.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
+    o.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int);
     rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/false, &o);
+    o.staged = spmm_staged(L, NV, h, n_table_rows);
     if (rc >= 0) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &o);
   });
   if (rc < 0) return -rc;
@@ -910,7 +933,7 @@ int graphop_plan_sweep_info(const graphop_plan_t* plan, int sweep, graphop_sweep
   GO_CHECK_ARG(plan && out, "plan_sweep_info: NULL pointer");
   const Sweep* s = plan_sweep_at(plan, sweep);
   GO_CHECK_ARG(s != nullptr, "plan_sweep_info: no window structure %d", sweep);
-  out->win_cols = s->win_cols; out->W = s->W; out->T = s->T; out->V = s->V; out->reserved = 0;
+  out->win_cols = s->win_cols; out->W = s->W; out->T = s->T; out->V = s->V; out->n_dealt = s->n_dealt;
   return GRAPHOP_OK;
 }
 
@@ -970,6 +993,29 @@ int graphop_plan_import_sweep(graphop_plan_t* plan, const graphop_sweep_info_t* 
   GO_TRY(check_not_capturing((hipStream_t)stream, "plan_import_sweep"));
   return plan_import_sweep(plan, info->W, info->win_cols, info->T, info->V, vr_row, wp_lo, wp_hi,
                            (hipStream_t)stream);
+}
+
+int graphop_plan_sweep_dealt(const graphop_plan_t* plan, int sweep, int i, int32_t* L, int32_t* K) {
+  GO_CHECK_ARG(plan && L && K, "plan_sweep_dealt: NULL pointer");
+  const Sweep* s = plan_sweep_at(plan, sweep);
+  GO_CHECK_ARG(s != nullptr && i >= 0 && i < s->n_dealt, "plan_sweep_dealt: no layout %d of window structure %d", i, sweep);
+  *L = s->dealt[i].L; *K = s->dealt[i].K;
+  return GRAPHOP_OK;
+}
+
+int graphop_plan_sweep_build_dealt(graphop_plan_t* plan, const graphop_sweep_info_t* info, int32_t L,
+                                   int32_t K, void* stream) {
+  GO_CHECK_ARG(plan && info, "plan_sweep_build_dealt: NULL pointer");
+  GO_CHECK_ARG(plan->idx32 != nullptr, "plan_sweep_build_dealt: the plan has no 32-bit mirrors");
+  for (int i = 0; i < plan_n_sweeps(plan); ++i) {
+    const Sweep* s = plan_sweep_at(plan, i);
+    if (s->W == info->W && s->win_cols == info->win_cols && s->T == info->T) {
+      const Sweep::Dealt* d = nullptr;
+      return plan_get_dealt(plan, s, L, K, (hipStream_t)stream, &d);
+    }
+  }
+  set_error("plan_sweep_build_dealt: no window structure W=%d T=%d", (int)info->W, (int)info->T);
+  return GRAPHOP_ERR_INVALID_ARGUMENT;
 }
 
 void graphop_plan_destroy(graphop_plan_t* plan) {

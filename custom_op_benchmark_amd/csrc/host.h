@@ -24,7 +24,7 @@ struct Tuning {
   int mall_window_kb;   // window size for tables beyond the Infinity Cache
   int max_windows;
   int sweep_min_kb;     // tables smaller than this are L2-friendly enough for the chunk drivers
-  int sweep_bpc;        // resident blocks per CU for the sweep drivers
+  int sweep_bpc;        // resident blocks per CU for the sweep drivers (3: with staged ids 2 % faster than the 4 the kernels are compiled for)
   int sweep_k;          // vrows per lane group (0 = auto)
   int vrow_t;           // vrow length cap (0 = auto from the mean row length)
   int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
@@ -42,8 +42,8 @@ struct Tuning {
   int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
   int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
   int attn_bpc;           // resident workgroups per CU of the fused kernels
-  int staged_ids;         // window-owner SDDMM: plan-time deal + contiguous ids staged through LDS (measured: no gain on
-                          // the real passes, 1.80 vs 1.74 ms, although the all-L2-hit model gains 29 %; off, kept as a knob)
+  int staged_ids;         // window-owner passes: plan-time deal + contiguous ids staged through LDS (IdStage);
+                          // bit 0: SDDMM, bit 1: SpMM (both orientations), bit 2: the fused backward passes
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int n_cu;
@@ -53,7 +53,7 @@ struct Tuning {
     mall_window_kb = env_int("GRAPHOP_MALL_WINDOW_KB", 32768);
     max_windows = env_int("GRAPHOP_MAX_WINDOWS", 128);
     sweep_min_kb = env_int("GRAPHOP_SWEEP_MIN_KB", 4608);
-    sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 4);
+    sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 3);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
     sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
@@ -71,7 +71,7 @@ struct Tuning {
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
     attn_rows = env_int("GRAPHOP_ATTN_ROWS", -1);
-    staged_ids = env_int("GRAPHOP_STAGED_IDS", 0);
+    staged_ids = env_int("GRAPHOP_STAGED_IDS", 7);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
     n_cu = 256;
     int dev = 0;

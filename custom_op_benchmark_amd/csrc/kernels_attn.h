@@ -54,13 +54,15 @@ __global__ __launch_bounds__(kFastBlock) void k_attn_pack(
 // One lane group's strip of a (window, vrow tile) task.  `own` = the group's K packed own rows in
 // LDS ([K][2*NV][L] float4, a straight copy of the packed table rows).  `sink(k, acc0, acc1)`
 // receives the finished sums of granule k (group-uniform call): acc0 = sum ds * X0, acc1 = sum a * X1.
-template <int L, int NV, bool COL, bool OFF32, typename Sink, typename Stage>
+// STAGED: the neighbour ids come from the dealt layout through IdStage (kernels_fast.h) -- idx32 is
+// then ids_w, pos0 the strip's start in it and idbuf the group's LDS ring.
+template <int L, int NV, bool COL, bool OFF32, bool STAGED, typename Sink, typename Stage>
 __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
                                                const float4* __restrict__ own, int lo_l, int n_l,
                                                const int* __restrict__ idx32,
                                                const float* __restrict__ XT,
                                                const float4* __restrict__ stats4, float4 own_st,
-                                               int l) {
+                                               int l, int pos0 = 0, int* __restrict__ idbuf = nullptr) {
   constexpr int SB = AttnCfg<L, NV>::SB;
   constexpr int F4 = L * NV;
   constexpr unsigned ROWB = 2u * F4 * 16u;   // bytes of a packed row
@@ -86,15 +88,25 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
   // the row statistics of the gathered row are a second dependent load, so stage A runs two batches
   // ahead and stage B (the 16-B statistics) one batch ahead.
   struct Pre { int k, src, live; float4 st; };
+  IdStage<L, 1> ids;
+  if constexpr (STAGED) ids.init(idx32, nullptr, pos0, idbuf, l, m.total);
   auto stage_a = [&](int jbase, Pre& p) {
     const int j = jbase + l;
+    const int jc = j < m.total ? j : m.total - 1;
     int e;
-    m.locate<L>(j < m.total ? j : m.total - 1, p.k, e);   // every lane takes part in the shuffles
+    m.locate<L>(jc, p.k, e);   // every lane takes part in the shuffles
     p.live = (l < SB && j < m.total) ? 1 : 0;
     p.src = 0;
     // slots past the end re-read the strip's last neighbour id with weights 0, so the batch loop
     // needs no per-slot clamping
-    if (l < SB) p.src = idx32[e];
+    if constexpr (STAGED) {
+      if (jbase < m.total) {   // group-uniform
+        ids.advance(jbase);
+        p.src = ids.id(jc);
+      }
+    } else {
+      if (l < SB) p.src = idx32[e];
+    }
   };
   auto stage_b = [&](Pre& p) {
     if constexpr (COL) {
@@ -200,29 +212,33 @@ __device__ __forceinline__ void attn_bwd_strip(Sink&& sink, Stage&& stage_rows,
 //   COL = false: OWN = (Q | dO) packed [n_rows][2F], XT = (K | V) packed, out0 = dQ
 //   COL = true : OWN = (K | V) packed [n_cols][2F], XT = (Q | dO) packed, out0 = dK, out1 = dV
 // stats4[i] = (m_i, linv_i, D_i, 0) per ROW i of the attention matrix in both passes.
-template <int L, int NV, bool COL, bool OFF32, int BPC>
+template <int L, int NV, bool COL, bool OFF32, int BPC, bool STAGED = false>
 __global__ __launch_bounds__(kFastBlock, BPC) void k_attn_bwd_wown_f32(
     SweepView s, const float* __restrict__ OWN, const float* __restrict__ XT,
     const float4* __restrict__ stats4, float* __restrict__ out0, float* __restrict__ out1) {
   extern __shared__ float4 lds[];
   constexpr i64 F4 = (i64)L * NV;
   constexpr int GW = kWave / L;
+  constexpr int GPB = kFastBlock / L;
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
   float4* mine = lds + (i64)g_in_blk * s.K * 2 * F4;   // [K][2*NV][L]
+  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * s.K * 2 * F4) + g_in_blk * StageCfg<L, 1>::kLdsIntsPerGroup;
   const int tile = GW * s.K;
-  WownQueue queue(s, (s.V + tile - 1) / tile);
+  const int tiles = (s.V + tile - 1) / tile;
+  WownQueue queue(s, tiles);
   int w, t;
   bool more = queue.pull(w, t);
   int raw = more ? queue.issue() : -1;
   WownTask<L> cur, nxt;
-  if (more) cur.load(s, w, t, tile);
+  cur.pos = 0;
+  if (more) { if constexpr (STAGED) cur.load_dealt(s, w, t, tile, tiles); else cur.load(s, w, t, tile); }
   while (more) {
     int wn = 0, tn = 0;
     const bool more_n = queue.resolve(raw, wn, tn);
     raw = more_n ? queue.issue() : -1;
-    nxt.nv = 0; nxt.lo = nxt.hi = nxt.row = 0;
-    if (more_n) nxt.load(s, wn, tn, tile);
+    nxt.nv = 0; nxt.lo = nxt.hi = nxt.row = nxt.pos = 0;
+    if (more_n) { if constexpr (STAGED) nxt.load_dealt(s, wn, tn, tile, tiles); else nxt.load(s, wn, tn, tile); }
     float4 own_st = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (!COL) own_st = stats4[cur.row];   // lane k: statistics of the group's k-th vrow
     auto stage_rows = [&]() {   // packed own rows of this task's non-empty granules -> LDS
@@ -244,8 +260,12 @@ __global__ __launch_bounds__(kFastBlock, BPC) void k_attn_bwd_wown_f32(
       if constexpr (COL) atomic_flush_dense<L, NV>(out1, r, acc1, l);
 #endif
     };
-    attn_bwd_strip<L, NV, COL, OFF32>(to_out, stage_rows, mine, cur.lo, cur.hi - cur.lo, s.idx32, XT,
-                                      stats4, own_st, l);
+    if constexpr (STAGED)
+      attn_bwd_strip<L, NV, COL, OFF32, true>(to_out, stage_rows, mine, cur.lo, cur.hi - cur.lo, s.ids_w, XT,
+                                              stats4, own_st, l, __shfl(cur.pos, 0, L), idbuf);
+    else
+      attn_bwd_strip<L, NV, COL, OFF32, false>(to_out, stage_rows, mine, cur.lo, cur.hi - cur.lo, s.idx32, XT,
+                                               stats4, own_st, l);
     cur = nxt;
     more = more_n;
   }

@@ -545,81 +545,122 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
   if constexpr (!EID_ID) t_eid.retire();
 }
 
-// Staged SDDMM strip (h == 1, identity eid, 32-bit offsets; dealt layout): the strip's neighbour ids
-// are ONE contiguous 16-byte-aligned run of ids_w starting at pos0.  They are fetched a segment
-// (SEG slots) at a time with dwordx4 loads, a segment ahead, parked in registers, written to the
-// group's LDS buffer at the segment switch and read from there one per lane and batch: between two
-// batches of row requests the vector memory pipeline sees no small load to wait behind
-// (tools/microbench/sweep_model.hip: 1.66 -> 1.18 ms for the Reddit-shape edge count).
-template <int L>
+// ---- staged id streams (dealt layouts) ---------------------------------------------------------------
+// With a dealt layout (plan.hip, Sweep::Dealt) the neighbour ids -- and edge ids -- of a lane group's
+// strip are ONE contiguous 16-byte-aligned run starting at pos0.  IdStage fetches them a segment
+// (SEG slots) at a time with dwordx4 loads, parks the segment in the group's LDS ring (two segments
+// per stream) and hands them out by flat slot: between two batches of row requests the vector memory
+// pipeline then sees no small load of ids (tools/microbench/sweep_model.hip: 1.66 -> 1.18 ms for the
+// Reddit-shape edge count when every gather hits L2; the shipped SDDMM passes gain 4-5 %).
+// Protocol: init() once; advance(jb) at every batch start (it acts when jb reaches the middle of a
+// segment: the next segment becomes readable, the one after is requested); id(j) / eid(j) for any
+// flat slot j in [jb, jb + SEG / 2].
+template <int L, int NS = 1>
 struct StageCfg {
-  static constexpr int SEG = 4 * L > 128 ? 4 * L : 128;   // slots per segment
-  static constexpr int NQ = SEG / (4 * L);                // int4 per lane and segment
+  static constexpr int kMin = NS == 1 ? 128 : 64;         // two streams: half the segment, same registers
+  static constexpr int SEG = 4 * L > kMin ? 4 * L : kMin; // slots per segment (power of two)
+  static constexpr int NQ = SEG / (4 * L);                // dwordx4 per lane, segment and stream
+  static constexpr int kLdsIntsPerGroup = NS * 2 * SEG;
 };
+template <int L, int NS>
+struct IdStage {
+  static constexpr int SEG = StageCfg<L, NS>::SEG, NQ = StageCfg<L, NS>::NQ;
+  typedef int vint4 __attribute__((ext_vector_type(4)));   // (HIP's int4 struct keeps the array in scratch)
+  vint4 nx[NS][NQ];
+  const int* base[NS];   // wave-uniform
+  int at;                // this lane's first id of segment 0 (element index: pos0 + 4 * lane)
+  int* buf;              // [NS][2][SEG]
+  int l, total;
+  __device__ __forceinline__ void load(int seg) {
+    if (seg >= total) return;   // group-uniform
+    static_for<NS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      static_for<NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        nx[st][q] = *reinterpret_cast<const vint4*>(base[st] + ((i64)at + seg + q * 4 * L));
+      });
+    });
+  }
+  __device__ __forceinline__ void park(int seg) {
+    if (seg >= total) return;
+    static_for<NS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      static_for<NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        *reinterpret_cast<vint4*>(buf + (st * 2 + ((seg / SEG) & 1)) * SEG + q * 4 * L + l * 4) = nx[st][q];
+      });
+    });
+  }
+  __device__ __forceinline__ void init(const int* __restrict__ ids_w, const int* __restrict__ eids_w, int pos0,
+                                       int* group_buf, int lane, int n_total) {
+    buf = group_buf; l = lane; total = n_total;
+    base[0] = ids_w;
+    if constexpr (NS > 1) base[1] = eids_w;
+    at = pos0 + lane * 4;
+    load(0);
+    park(0);
+    load(SEG);
+  }
+  __device__ __forceinline__ void advance(int jb) {
+    if ((jb & (SEG - 1)) == SEG / 2) {
+      const int seg = jb & ~(SEG - 1);
+      park(seg + SEG);
+      load(seg + 2 * SEG);
+    }
+  }
+  __device__ __forceinline__ int id(int j) const { return buf[((j / SEG) & 1) * SEG + (j & (SEG - 1))]; }
+  __device__ __forceinline__ int eid(int j) const { return buf[(2 + ((j / SEG) & 1)) * SEG + (j & (SEG - 1))]; }
+};
+
+// Staged SDDMM strip (h == 1, identity eid, 32-bit offsets; dealt layout).
 template <int L, int NV, typename Stage>
 __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ rowsA, int lo_l, int n_l,
                                                    int pos0, const int* __restrict__ ids_w,
                                                    int* __restrict__ idbuf, const float* __restrict__ B,
                                                    float* __restrict__ y, int l, Stage&& stage_rows) {
   constexpr int SB = StripCfg<L, NV>::SB;
-  constexpr int SEG = StageCfg<L>::SEG, NQ = StageCfg<L>::NQ;
   constexpr i64 F4 = (i64)L * NV;
   StripMap m;
   m.init<L>(lo_l, n_l, l);
   if (m.total == 0) return;
-  int4 nx[NQ];
-  auto fetch = [&](int seg) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      nx[q] = *reinterpret_cast<const int4*>(ids_w + pos0 + seg + q * 4 * L + l * 4);
-  };
-  fetch(0);
+  IdStage<L, 1> ids;
+  ids.init(ids_w, nullptr, pos0, idbuf, l, m.total);
   stage_rows();
-  float a[1];
-  (void)a;
   float prev_res = 0.f;
   int prev_e = -1;
   const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
-  for (int seg = 0; seg < m.total; seg += SEG) {
+  for (int jb = 0; jb < m.total; jb += SB) {
+    const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
+    ids.advance(jb);
+    const int j = (jb + l) < m.total ? jb + l : m.total - 1;   // lanes past the end re-read the last slot
+    const int nsrc = ids.id(j);
+    int nk, e;
+    m.locate<L>(j, nk, e);
+    const int my_e = (l < nb) ? e : -1;
+    const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
+    const unsigned my_off = (unsigned)nsrc * (unsigned)(F4 * 16);
+    float4 b[SB][NV];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned o = group_bcast<L, u>(my_off);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) *reinterpret_cast<int4*>(idbuf + q * 4 * L + l * 4) = nx[q];
-    const int seg_end = (m.total - seg) < SEG ? m.total : seg + SEG;
-    bool ahead = seg + SEG < m.total;
-    for (int jb = seg; jb < seg_end; jb += SB) {
-      const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
-      const int nsrc = idbuf[(jb - seg) + (l < SB ? l : 0)];
-      int nk, e;
-      {
-        const int j = jb + l;
-        m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
-      }
-      const int my_e = (l < nb) ? e : -1;
-      const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
-      const unsigned my_off = (unsigned)nsrc * (unsigned)(F4 * 16);
-      float4 b[SB][NV];
-      static_for<SB>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const unsigned o = group_bcast<L, u>(my_off);
+      for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
+    });
+    if (prev_e >= 0) y[prev_e] = prev_res;
+    float part[SB];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned ko = group_bcast<L, u>(my_koff);
+      float4 av[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
-      });
-      if (prev_e >= 0) y[prev_e] = prev_res;
-      if (ahead) { fetch(seg + SEG); ahead = false; }   // next segment's ids, behind this batch's row requests
-      float part[SB];
-      static_for<SB>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const unsigned ko = group_bcast<L, u>(my_koff);
-        float4 av[NV];
+      for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
+      float p = dot4(av[0], b[u][0]);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
-        float p = dot4(av[0], b[u][0]);
-#pragma unroll
-        for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
-        part[u] = p;
-      });
-      prev_res = group_dots_to_owner<L, SB>(part, l);
-      prev_e = my_e;
-    }
+      for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
+      part[u] = p;
+    });
+    prev_res = group_dots_to_owner<L, SB>(part, l);
+    prev_e = my_e;
   }
   if (prev_e >= 0) y[prev_e] = prev_res;
 }
@@ -721,6 +762,82 @@ __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
         acc[v].y = fmaf(ww, x[u][v].y, acc[v].y);
         acc[v].z = fmaf(ww, x[u][v].z, acc[v].z);
         acc[v].w = fmaf(ww, x[u][v].w, acc[v].w);
+      }
+    });
+  }
+  spill();
+}
+
+// Staged SpMM strip (h == 1, 32-bit offsets; dealt layout): spmm_strip with the neighbour ids (and,
+// when eid is not the identity, the edge ids) taken from IdStage instead of per-batch loads.  The
+// weights are still loads: w[e] of the granule's slot run (identity eid) or the gather w[eid].
+template <int L, int NV, bool EID_ID, typename Sink>
+__device__ __forceinline__ void spmm_strip_staged(Sink&& sink, int lo_l, int n_l, int pos0,
+                                                  const int* __restrict__ ids_w,
+                                                  const int* __restrict__ eids_w, int* __restrict__ idbuf,
+                                                  const float* __restrict__ w,
+                                                  const float* __restrict__ X, int l) {
+  constexpr int SB = StripCfg<L, NV>::SB;
+  constexpr i64 F4 = (i64)L * NV;
+  StripMap m;
+  m.init<L>(lo_l, n_l, l);
+  if (m.total == 0) return;
+  IdStage<L, EID_ID ? 1 : 2> ids;
+  ids.init(ids_w, eids_w, pos0, idbuf, l, m.total);
+  float4 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k_cur = -1;
+  auto spill = [&]() {
+    if (k_cur >= 0) {
+      sink(k_cur, acc);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // weight pipeline: identity eid -> w[e] one batch ahead; otherwise the gather w[eid] one batch ahead
+  struct Pre { int k, src; float w; };
+  auto stage = [&](int jbase, Pre& p) {
+    const int jj = jbase + l;
+    const bool live = l < SB && jj < m.total;
+    const int j = jj < m.total ? jj : m.total - 1;
+    int e;
+    m.locate<L>(j, p.k, e);
+    p.src = ids.id(j);          // slots past the end re-read the last neighbour with weight 0
+    p.w = 0.f;
+    if (live) p.w = w[EID_ID ? e : ids.eid(j)];
+  };
+  Pre p1;
+  stage(0, p1);
+  for (int jb = 0; jb < m.total; jb += SB) {
+    const int my_k = p1.k;
+    const unsigned my_off = (unsigned)p1.src * (unsigned)(F4 * 16);
+    const float my_w = p1.w;
+    float4 x[SB][NV];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned o = group_bcast<L, u>(my_off);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
+    });
+    if (jb + SB < m.total) {   // next batch: its weight load stays in flight behind this batch's row requests
+      ids.advance(jb + SB);
+      stage(jb + SB, p1);
+    }
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int kt = group_bcast<L, u>(my_k);
+      if (kt != k_cur) {   // group-uniform
+        spill();
+        k_cur = kt;
+      }
+      const float w1 = group_bcast<L, u>(my_w);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        acc[v].x = fmaf(w1, x[u][v].x, acc[v].x);
+        acc[v].y = fmaf(w1, x[u][v].y, acc[v].y);
+        acc[v].z = fmaf(w1, x[u][v].z, acc[v].z);
+        acc[v].w = fmaf(w1, x[u][v].w, acc[v].w);
       }
     });
   }
@@ -1136,7 +1253,7 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, true, true)) void k_sddmm
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
   float4* mine = lds + (i64)g_in_blk * s.K * F4;  // [K][NV][L]
-  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * s.K * F4) + g_in_blk * StageCfg<L>::SEG;
+  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * s.K * F4) + g_in_blk * StageCfg<L, 1>::kLdsIntsPerGroup;
   const int tile = GW * s.K;
   const int tiles = (s.V + tile - 1) / tile;
   WownQueue queue(s, tiles);
@@ -1194,6 +1311,39 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_spmm_wo
       atomic_flush_dense<L, NV>(out, __shfl(row_l, k, L), acc, l);
     };
     spmm_strip<L, NV, H1, EID_ID, OFF32>(to_out, cur.lo, cur.hi - cur.lo, s.eid32, s.idx32, wgt, X, h, hv, l);
+    cur = nxt;
+    more = more_n;
+  }
+}
+
+// Staged form (h == 1, table < 4 GiB, dealt layout in the view).
+template <int L, int NV, bool EID_ID>
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, true, true)) void k_spmm_wown_staged_f32(
+    SweepView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
+  extern __shared__ float4 lds[];
+  constexpr int GW = kWave / L;
+  const int l = threadIdx.x % L;
+  int* idbuf = reinterpret_cast<int*>(lds) + (threadIdx.x / L) * StageCfg<L, EID_ID ? 1 : 2>::kLdsIntsPerGroup;
+  const int tile = GW * s.K;
+  const int tiles = (s.V + tile - 1) / tile;
+  WownQueue queue(s, tiles);
+  int w, t;
+  bool more = queue.pull(w, t);
+  int raw = more ? queue.issue() : -1;
+  WownTask<L> cur, nxt;
+  if (more) cur.load_dealt(s, w, t, tile, tiles);
+  while (more) {
+    int wn = 0, tn = 0;
+    const bool more_n = queue.resolve(raw, wn, tn);
+    raw = more_n ? queue.issue() : -1;
+    nxt.nv = 0; nxt.lo = nxt.hi = nxt.row = nxt.pos = 0;
+    if (more_n) nxt.load_dealt(s, wn, tn, tile, tiles);
+    const int row_l = cur.row;
+    auto to_out = [&](int k, const float4 (&acc)[NV]) {
+      atomic_flush_dense<L, NV>(out, __shfl(row_l, k, L), acc, l);
+    };
+    spmm_strip_staged<L, NV, EID_ID>(to_out, cur.lo, cur.hi - cur.lo, __shfl(cur.pos, 0, L), s.ids_w, s.eids_w,
+                                     idbuf, wgt, X, l);
     cur = nxt;
     more = more_n;
   }

@@ -673,10 +673,10 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
   const i64 tiles = ceil_div((i64)s->V, tile);
   const i64 tasks = tiles * s->W, strips = tasks * GW;
   const i64 E = p->info.n_edges;
-  if (tasks * tile >= 0x7fffffffLL || E + 4 * strips + 64 >= 0x7fffffffLL) return GRAPHOP_OK;
+  if (tasks * tile >= 0x7fffffffLL || E + 4 * strips + 1024 >= 0x7fffffffLL) return GRAPHOP_OK;
   Sweep::Dealt d;
   d.L = L; d.K = K; d.tiles = (int)tiles;
-  d.n_ids = E + 3 * strips + 64;   // upper bound: every strip padded to 4 ints, slack for the last wide load
+  d.n_ids = E + 3 * strips + 1024;   // upper bound: every strip padded to 4 ints; slack: a strip's last segment is fetched whole
   DevBuf len, tmp;
   GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(strips + 1), st));
   const bool with_eid = !p->info.eid_identity && p->eid32;

@@ -49,7 +49,7 @@ extern "C" {
 #define GRAPHOP_API
 #endif
 
-#define GRAPHOP_ABI_VERSION 3
+#define GRAPHOP_ABI_VERSION 4
 
 #define GRAPHOP_F32 0
 #define GRAPHOP_F64 1
@@ -171,7 +171,7 @@ typedef struct graphop_sweep_info {
   int32_t W;        /* windows */
   int32_t T;        /* row pieces are at most T slots long */
   int32_t V;        /* row pieces ("vrows") */
-  int32_t reserved;
+  int32_t n_dealt;  /* window-major id layouts built on this structure so far (export: see below) */
 } graphop_sweep_info_t;
 GRAPHOP_API int graphop_plan_n_sweeps(const graphop_plan_t* plan);
 GRAPHOP_API int graphop_plan_sweep_info(const graphop_plan_t* plan, int sweep, graphop_sweep_info_t* out);
@@ -186,6 +186,15 @@ GRAPHOP_API int graphop_plan_import(const int64_t* row, const int64_t* indptr, c
 GRAPHOP_API int graphop_plan_import_sweep(graphop_plan_t* plan, const graphop_sweep_info_t* info,
                               const int32_t* vr_row, const int32_t* wp_lo, const int32_t* wp_hi,
                               void* stream);
+/* The window-owner kernels read their neighbour ids from a window-major copy ("dealt layout": the
+ * granules of every task dealt to the lane groups once, each group's ids one contiguous run), one
+ * per lane-group geometry (L lanes per group, K row pieces per group).  It is a pure function of
+ * the window structure and the 32-bit mirrors, so a container stores only the (L, K) pairs:
+ * graphop_plan_sweep_dealt reads the i-th pair of a structure, graphop_plan_sweep_build_dealt
+ * re-creates the layout on the (imported) structure that matches `info`. */
+GRAPHOP_API int graphop_plan_sweep_dealt(const graphop_plan_t* plan, int sweep, int i, int32_t* L, int32_t* K);
+GRAPHOP_API int graphop_plan_sweep_build_dealt(graphop_plan_t* plan, const graphop_sweep_info_t* info, int32_t L,
+                                   int32_t K, void* stream);
 
 /* ---- SDDMM: maskedmm_csr_forward(row, indptr, eid, indices, A, B) -> y ----------------------
  * replaces graphop.cpp:16-30 / graphop_kernel.cu:269-304 (kernel :40-55).

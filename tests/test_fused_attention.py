@@ -66,8 +66,8 @@ def force_sweep():
     _lib.clear_plan_cache()
     yield
     _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0); _lib.tune("max_windows", 128)
-    _lib.tune("sweep_bpc", 4); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
-    _lib.tune("attn_bpc", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2)
+    _lib.tune("sweep_bpc", 3); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
+    _lib.tune("attn_bpc", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2); _lib.tune("staged_ids", 7)
     _lib.clear_plan_cache()
 
 
@@ -95,10 +95,12 @@ def test_fused_step_fp64(dev, d):
 
 @pytest.mark.parametrize("d,scale,k,bpc", [(64, 2, 0, 0), (64, 1, 2, 1), (16, 2, 0, 1), (32, 1, 0, 0),
                                            (128, 2, 0, 0), (256, 1, 0, 0), (512, 2, 0, 0), (1024, 1, 0, 0)])
-def test_fused_window_passes_vs_oracle(dev, force_sweep, d, scale, k, bpc):
+@pytest.mark.parametrize("staged", [0, 7])
+def test_fused_window_passes_vs_oracle(dev, force_sweep, d, scale, k, bpc, staged):
     """The fused window-owner passes (forced by tiny windows): rows longer than vrow_t are cut into
     pieces merged by atomics, empty rows / windows occur, non-square graph, several tasks per wave."""
     _lib.tune("attn_window_scale", scale); _lib.tune("attn_k", k); _lib.tune("attn_bpc", bpc)
+    _lib.tune("staged_ids", staged)                  # ids per batch / staged through LDS (d <= 64 in the fused passes)
     _lib.tune("window_kb", 4 * max(1, d // 64))      # a few packed rows per window at every width
     n = 120 if d >= 512 else 1500
     g = random_graph(n, n + 41, 10 * n, seed=77 + d, chunk_size=32, zero_rows=0.15, hub=900)

@@ -368,7 +368,7 @@ def force_sweep():
     _lib.clear_plan_cache()
     yield
     _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
-    _lib.tune("sweep_bpc", 4); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
+    _lib.tune("sweep_bpc", 3); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
     _lib.tune("sweep_mode", 1)
     _lib.clear_plan_cache()
 
@@ -391,12 +391,14 @@ def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d, mode):
         close(got[k], want[k])
 
 
+@pytest.mark.parametrize("staged", [0, 3])
 @pytest.mark.parametrize("d", [16, 32, 64, 256, 1024])
-def test_staged_id_strips_vs_oracle(dev, force_sweep, d):
-    """Window-owner SDDMM with the plan-time deal and ids staged through LDS (knob staged_ids, off by
-    default): same graph as above; strips longer than one 128-slot segment, empty granules, the
-    padded tail of a strip."""
-    _lib.tune("staged_ids", 1); _lib.tune("sweep_bpc", 1 if d <= 64 else 4)
+def test_id_staging_on_and_off_vs_oracle(dev, force_sweep, d, staged):
+    """Window-owner SDDMM / SpMM (row- and column-major) with the plan-time deal and ids staged through
+    LDS (knob staged_ids, the default) and with the per-batch id loads (staged_ids = 0): same graph as
+    above; strips longer than a segment, empty granules, the padded tail of a strip, two id streams
+    in the column-major passes."""
+    _lib.tune("staged_ids", staged); _lib.tune("sweep_bpc", 1 if d <= 64 else 4)
     _lib.tune("window_kb", 4 * max(1, d // 64)); _lib.clear_plan_cache()      # a few rows per window at every width
     try:
         n = 120 if d >= 512 else 1500
@@ -413,9 +415,13 @@ def test_staged_id_strips_vs_oracle(dev, force_sweep, d):
         torch.cuda.synchronize()
         kernels = {r.get("kernel") for r in _lib.profile_read().values()}
         _lib.profile_enable(False)
-        assert "k_sddmm_wown_staged_f32" in kernels, kernels
+        if staged:
+            assert "k_sddmm_wown_staged_f32" in kernels, kernels
+            assert d > 128 or "k_spmm_wown_staged_f32" in kernels, kernels
+        else:
+            assert {"k_sddmm_wown_f32", "k_spmm_wown_f32"} <= kernels, kernels
     finally:
-        _lib.tune("staged_ids", 0); _lib.clear_plan_cache()
+        _lib.tune("staged_ids", 7); _lib.clear_plan_cache()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -510,7 +516,7 @@ def test_fuzz_shapes_and_paths(dev, seed):
             close(got[k], want[k], rtol=2e-4, atol=2e-5)
     finally:
         for key, val in (("sweep_min_kb", 4608), ("sweep_min_granule", 4), ("max_windows", 128), ("window_kb", 4096),
-                         ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 4), ("sweep_prefetch", 0),
+                         ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 3), ("sweep_prefetch", 0),
                          ("transpose_scalars", 0), ("sweep_mode", 1)):
             _lib.tune(key, val)
         _lib.clear_plan_cache()

@@ -28,7 +28,7 @@ def test_default_geometry_medium_graph_vs_cpu_path(dev):
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     # the headline drivers ran, at the default geometry
-    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_wown_f32", prof
+    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_staged_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_wown_staged_f32", prof
     o0, dQ0, dK0, dV0 = torch_path.attention_step_blocked(g.src.cpu(), g.dst.cpu(), g.indptr_r.cpu(), Q.cpu(), K.cpu(),
                                                           V.cpu(), dO.cpu(), N, rows_per_block=2048)
     tol = dict(rtol=2e-4, atol=2e-5)
