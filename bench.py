@@ -459,7 +459,8 @@ def main():
         "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4),
                     "max": round(max(step_ms), 4), "method": "hipEvents around every timed step on the launch stream"},
         "config": cfg,
-        "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3)},
+        "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3),
+                  "plan_memory_MB": round(_lib.plan_memory_bytes() / 2**20, 1)},
         "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }

@@ -275,10 +275,12 @@ class Plan:
         return handle
 
     def prepare(self, dtype, n_table_rows, h, d, fused=True):
-        """Build every cached window structure ops on (n_table_rows, h, d) tensors will use."""
+        """Build every cached window structure ops on (n_table_rows, h, d) tensors will use.
+        fused: False / True (the plan may serve either side of the fused passes) / 2 (row-major side
+        only) / 3 (column-major side only)."""
         with torch.cuda.device(self.tensors[1].device):
             check(lib().graphop_plan_prepare(self.handle, dtype, int(n_table_rows), int(h), int(d),
-                                             1 if fused else 0, stream_of(self.tensors[1])))
+                                             int(fused), stream_of(self.tensors[1])))
 
     def __repr__(self):
         i = self.info

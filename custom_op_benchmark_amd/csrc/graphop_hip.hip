@@ -918,10 +918,12 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
   });
   if (rc < 0) return -rc;
   if (fused && h == 1) {
-    // the plan serves as the row-major side or as the column-major side of the fused passes: both
-    // use the same window geometry but may differ in the resident-grid term of the piece length
-    rc = attn_prepare_plan(plan, n_table_rows, d, false, st);
-    if (rc >= 0) rc = attn_prepare_plan(plan, n_table_rows, d, true, st);
+    // the plan serves as the row-major side (fused = 2), as the column-major side (3) or as either
+    // (1) of the fused passes: same window geometry, but the piece length and the dealt id layout
+    // differ with the resident grid of the pass
+    rc = 0;
+    if (fused != 3) rc = attn_prepare_plan(plan, n_table_rows, d, false, st);
+    if (rc >= 0 && fused != 2) rc = attn_prepare_plan(plan, n_table_rows, d, true, st);
     if (rc < 0) return -rc;
   }
   return GRAPHOP_OK;

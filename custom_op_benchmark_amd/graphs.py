@@ -191,8 +191,8 @@ def prepare(g, h=1, d=64, dtype=torch.float32, fused=True):
     code = _lib.F32 if dtype == torch.float32 else _lib.F64
     plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, g.n_dst)
     plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, g.n_src)
-    plan_r.prepare(code, g.n_dst, h, d, fused)      # the row-major side gathers the column-node table
-    plan_c.prepare(code, g.n_src, h, d, fused)
+    plan_r.prepare(code, g.n_dst, h, d, 2 if fused else 0)      # the row-major side gathers the column-node table
+    plan_c.prepare(code, g.n_src, h, d, 3 if fused else 0)
     return plan_r, plan_c
 
 

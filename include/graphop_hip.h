@@ -151,7 +151,8 @@ GRAPHOP_API void graphop_plan_destroy(graphop_plan_t* plan);
 
 /* Build now every cached structure the ops would otherwise build on first use for node tensors of
  * n_table_rows x (h*d) values gathered through this plan (the column-window structures of the
- * SDDMM-type, SpMM-type and -- fused != 0 -- fused attention passes).  After it no op call on
+ * SDDMM-type, SpMM-type and -- fused != 0 -- fused attention passes: fused = 1 for either side,
+ * 2 when the plan is only ever the row-major side, 3 the column-major side).  After it no op call on
  * these shapes allocates or synchronises: required before capturing the ops into a HIP graph
  * (an op that would have to build one during capture fails with GRAPHOP_ERR_INVALID_ARGUMENT). */
 GRAPHOP_API int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, int64_t h,
