@@ -805,7 +805,11 @@ __device__ __forceinline__ void spmm_strip_staged(Sink&& sink, int lo_l, int n_l
     m.locate<L>(j, p.k, e);
     p.src = ids.id(j);          // slots past the end re-read the last neighbour with weight 0
     p.w = 0.f;
+#if defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 16)   // measurement build: no weight loads
+    if (live) p.w = 1.0f + (float)e * 0.f;
+#else
     if (live) p.w = w[EID_ID ? e : ids.eid(j)];
+#endif
   };
   Pre p1;
   stage(0, p1);
