@@ -424,6 +424,45 @@ def test_id_staging_on_and_off_vs_oracle(dev, force_sweep, d, staged):
         _lib.tune("staged_ids", 7); _lib.clear_plan_cache()
 
 
+@pytest.mark.parametrize("k", [1, 4])
+@pytest.mark.parametrize("deg", [15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200])
+def test_staged_strips_at_segment_boundaries(dev, force_sweep, deg, k):
+    """Strips whose slot count sits on, just below and just above the staging boundaries (half a
+    segment = 64, a segment = 128, a batch = 16): every row has exactly `deg` neighbours in window 0
+    and deg - 1 in window 1, rows kept whole, k rows per lane group -> strips of k*deg and k*(deg-1)
+    slots; SDDMM, both SpMM orientations and the fused backward, vs the oracle."""
+    n, n_cols = 96, 512
+    gen = torch.Generator().manual_seed(deg * 7 + k)
+    src, dst = [], []
+    for i in range(n):
+        for lo, cnt in ((0, deg), (256, deg - 1)):
+            src.append(torch.full((cnt,), i, dtype=torch.int64))
+            dst.append(lo + torch.randperm(256, generator=gen)[:cnt].sort().values)
+    g = graphs.graph_from_coo(torch.cat(src), torch.cat(dst), n_cols, n_cols, chunk_size=32)
+    _lib.tune("window_kb", 64); _lib.tune("vrow_t", 4096); _lib.tune("sweep_k", k); _lib.tune("attn_k", k)
+    _lib.tune("attn_window_scale", 1); _lib.tune("staged_ids", 7); _lib.clear_plan_cache()     # 256 rows of 256 B per window
+    try:
+        inp = rand_inputs(g, 1, 64, seed=deg, normal=True)
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+        gd = g.to(dev)
+        args = [inp[x].to(dev) for x in ("Q", "K", "V", "dO")]
+        got = hip_step(gd, *args)
+        for key in ("s", "a", "o", "dQ", "dK", "dV"):
+            close(got[key], want[key])
+        _lib.profile_enable(True)
+        hip_step(gd, *args)
+        torch.cuda.synchronize()
+        kernels = {r.get("kernel") for r in _lib.profile_read().values()}
+        _lib.profile_enable(False)
+        assert {"k_sddmm_wown_staged_f32", "k_spmm_wown_staged_f32"} <= kernels, kernels
+        q, kk, v = (t.clone().requires_grad_(True) for t in args[:3])
+        functions.fused_attention_step(gd, q, kk, v, args[3])
+        for key, grad in (("dQ", q.grad), ("dK", kk.grad), ("dV", v.grad)):
+            close(grad, want[key])
+    finally:
+        _lib.tune("sweep_k", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2); _lib.clear_plan_cache()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
     """Same inputs through both drivers: equal within fp32 re-association."""
@@ -502,6 +541,7 @@ def test_fuzz_shapes_and_paths(dev, seed):
         _lib.tune("sweep_drift", int(rng.choice([0, 1, 2, 3]))); _lib.tune("sweep_bpc", int(rng.choice([1, 2, 4])))
         _lib.tune("sweep_prefetch", int(rng.choice([0, 1]))); _lib.tune("transpose_scalars", int(rng.choice([0, 1])))
         _lib.tune("sweep_mode", int(rng.choice([0, 1])))
+        _lib.tune("staged_ids", int(rng.choice([0, 7, 7]))); _lib.tune("sweep_k", int(rng.choice([0, 0, 1, 2, 4, 8])))
     _lib.clear_plan_cache()
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
@@ -517,7 +557,7 @@ def test_fuzz_shapes_and_paths(dev, seed):
     finally:
         for key, val in (("sweep_min_kb", 4608), ("sweep_min_granule", 4), ("max_windows", 128), ("window_kb", 4096),
                          ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 3), ("sweep_prefetch", 0),
-                         ("transpose_scalars", 0), ("sweep_mode", 1)):
+                         ("transpose_scalars", 0), ("sweep_mode", 1), ("staged_ids", 7), ("sweep_k", 0)):
             _lib.tune(key, val)
         _lib.clear_plan_cache()
 
