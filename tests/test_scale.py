@@ -50,6 +50,35 @@ def test_default_geometry_medium_graph_vs_cpu_path(dev):
     torch.testing.assert_close(v2.grad.cpu(), dV0, **tol)
 
 
+def test_reddit_scale_fused_equals_unfused(dev):
+    """BASELINE config 2 at full size (N = 232,965, E = 114,615,892, d = 64), default knobs: the fused op
+    (recompute from row statistics, no E-sized backward intermediates) and the 8-function step are two
+    different kernel chains over the same graph; their o, dQ, dK, dV must agree to fp32 accuracy, and
+    the step's gradients must satisfy the adjoint identity <o, dO> expansion-free check
+    <Q, dQ> = <K, dK> (both equal sum_e s_e ds_e)."""
+    N, E = graphs.SHAPES["reddit"]
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    Q, K, V, dO = (torch.randn(N, 64, device=dev, generator=gen) / 8 for _ in range(4))
+    q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    s, a, o = functions.attention_step(g, q, k, v, dO)
+    q2, k2, v2 = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    _lib.profile_enable(True)
+    o2 = functions.fused_attention_step(g, q2, k2, v2, dO)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["attn_bwd_row"]["kernel"] == "k_attn_bwd_wown_f32" and "attn_bwd_col" in prof, prof
+    tol = dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(o2.detach(), o.detach(), **tol)
+    torch.testing.assert_close(q2.grad, q.grad, **tol)
+    torch.testing.assert_close(k2.grad, k.grad, **tol)
+    torch.testing.assert_close(v2.grad, v.grad, **tol)
+    lhs = (Q.double() * q.grad.double()).sum()
+    torch.testing.assert_close((K.double() * k.grad.double()).sum(), lhs, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close((K.double() * k2.grad.double()).sum(), (Q.double() * q2.grad.double()).sum(), rtol=1e-5, atol=1e-6)
+
+
 def test_products_scale_properties(dev):
     """BASELINE config 3 (h = 8, d = 128): ones -> d per head and degree; linearity; adjointness ties
     the forward and both backward passes of every gather op together; rows of the softmax sum to 1."""
