@@ -48,7 +48,7 @@ int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const
                    const graphop_plan* plan_c, hipStream_t st, bool dry_run, AttnFast* out) {
   const Tuning& t = tuning();
   if (!t.attn_fused || t.force_generic || dtype != GRAPHOP_F32 || h != 1) return 0;
-  if (!plan_r || !plan_c || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024) return 0;
+  if (!plan_r || !plan_c || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024 || d > t.attn_max_d) return 0;
   if (n_edges >= 0x7fffffffLL || n_q >= 0x7fffffffLL || n_k >= 0x7fffffffLL || n_edges == 0) return 0;
   if (plan_r->info.max_row >= n_q || plan_r->info.max_index >= n_k || plan_c->info.max_row >= n_k ||
       plan_c->info.max_index >= n_q)
@@ -71,7 +71,7 @@ inline char* at_offset(char* base, size_t off) { return base ? base + off : null
 // The chunk-driver form of the fused passes (k_attn_bwd_rows_f32): any fp32 one-head graph with plans
 // (they carry the id ranges that make the gathers safe); no window structure needed.
 bool attn_rows_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const graphop_plan* plan_r,
-                  const graphop_plan* plan_c) {
+                  const graphop_plan* plan_c, hipStream_t st) {
   const Tuning& t = tuning();
   if (!t.attn_fused || !t.attn_rows || t.force_generic || dtype != GRAPHOP_F32 || h != 1) return false;
   if (!plan_r || !plan_c || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024 || n_edges == 0) return false;
@@ -82,6 +82,21 @@ bool attn_rows_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const 
   // 16.0 -> 9.5 ms per step; papers100M-shape shard d=128 (E/N = 14.5: the 512-B rows dominate, the
   // step is HBM-gather-bound either way) 139 -> 152 ms, so that shape keeps the unfused passes.
   if (t.attn_rows < 0 && 180.0 * (double)n_edges <= 24.0 * (double)d * (double)(n_q + n_k)) return false;
+  // The chunk-driver passes gather at the rate of wherever the tables live; where the unfused passes
+  // would run on the column-window drivers (tables beyond the L2 with enough slots per window) those
+  // are faster than any chunk-driver form, and this shape was excluded from the fused window passes
+  // on purpose (attn_max_d): keep the unfused passes.
+  if (t.attn_rows < 0) {
+    int windows = 0;
+    GO_DISPATCH_LNV((int)d, {
+      SweepLaunch sl;
+      SweepOpts o;
+      o.dry_run = 1;
+      o.bpc = sweep_bpc(NV, true, t.sweep_mode == 1);
+      windows = choose_sweep(plan_r, n_k, L, NV, st, &sl, 0, false, &o);
+    });
+    if (windows != 0) return false;
+  }
   return plan_r->info.max_row < n_q && plan_r->info.max_index < n_k && plan_c->info.max_row < n_k &&
          plan_c->info.max_index < n_q;
 }
@@ -177,7 +192,7 @@ int launch_attn_pass(const char* tag, const SweepLaunch& sl, int F, i64 n_gather
 
 int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool col, hipStream_t st) {
   const Tuning& t = tuning();
-  if (!t.attn_fused || t.force_generic || !plan || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024) return 0;
+  if (!t.attn_fused || t.force_generic || !plan || d % 4 != 0 || !pow2(d) || d < 16 || d > 1024 || d > t.attn_max_d) return 0;
   int use = 0;
   GO_DISPATCH_LNV((int)d, {
     SweepLaunch sl;
@@ -209,7 +224,7 @@ int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, 
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
                                   /*dry_run=*/true, &af);
   if (fast < 0) return -fast;
-  if (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c))
+  if (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream))
     *bytes_out = (int64_t)FastWs(nullptr, n_q, n_k, h * d).total;
   else *bytes_out = (int64_t)SlowWs(nullptr, 4, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
   return GRAPHOP_OK;
@@ -223,7 +238,7 @@ int graphop_attention_backward_is_fused(int dtype, int64_t n_edges, int64_t n_q,
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream,
                                   /*dry_run=*/true, &af);
   if (fast < 0) return -fast;
-  *fused_out = (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c)) ? 1 : 0;
+  *fused_out = (fast == 1 || attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, plan_r, plan_c, (hipStream_t)stream)) ? 1 : 0;
   return GRAPHOP_OK;
 }
 
@@ -283,7 +298,7 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
   AttnFast af;
   const int fast = attn_fast_plan(dtype, h, d, n_edges, n_q, n_k, pr, pc, st, /*dry_run=*/false, &af);
   if (fast < 0) return -fast;
-  const bool rows_path = fast != 1 && attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, pr, pc);
+  const bool rows_path = fast != 1 && attn_rows_ok(dtype, h, d, n_edges, n_q, n_k, pr, pc, st);
   if (fast == 1 || rows_path) {
     const i64 F = d;   // h == 1
     FastWs ws((char*)workspace, n_q, n_k, F);

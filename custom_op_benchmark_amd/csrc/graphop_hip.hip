@@ -785,7 +785,7 @@ int graphop_tune(const char* key, int value) {
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
-      {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids},
+      {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {

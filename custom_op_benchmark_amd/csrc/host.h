@@ -44,6 +44,8 @@ struct Tuning {
   int attn_bpc;           // resident workgroups per CU of the fused kernels
   int staged_ids;         // window-owner passes: plan-time deal + contiguous ids staged through LDS (IdStage);
                           // bit 0: SDDMM, bit 1: SpMM (both orientations), bit 2: the fused backward passes
+  int attn_max_d;         // widest row (floats) the fused window passes are chosen for: beyond 64 the two-row gathers
+                          // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int n_cu;
@@ -71,6 +73,7 @@ struct Tuning {
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
     attn_rows = env_int("GRAPHOP_ATTN_ROWS", -1);
+    attn_max_d = env_int("GRAPHOP_ATTN_MAX_D", 64);
     staged_ids = env_int("GRAPHOP_STAGED_IDS", 7);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
     n_cu = 256;

@@ -63,11 +63,13 @@ def shuffled_chunk_arrays(g, seed):
 def force_sweep():
     _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 4); _lib.tune("vrow_t", 64)
     _lib.tune("max_windows", 512); _lib.tune("sweep_min_granule", 0)
+    _lib.tune("attn_max_d", 1024)          # by default the fused window passes are only chosen up to d = 64
     _lib.clear_plan_cache()
     yield
     _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0); _lib.tune("max_windows", 128)
     _lib.tune("sweep_bpc", 3); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
     _lib.tune("attn_bpc", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2); _lib.tune("staged_ids", 7)
+    _lib.tune("attn_max_d", 64)
     _lib.clear_plan_cache()
 
 
@@ -147,6 +149,20 @@ def test_fused_chunk_driver_passes_vs_oracle(dev, d, chunk_size, rows_sorted):
         assert not ({"attn_rows_row", "attn_rows_col"} & prof_tags(step))
     finally:
         _lib.tune("attn_rows", -1); _lib.clear_plan_cache()
+
+
+def test_fused_selection_follows_the_measured_rules(dev):
+    """Which form attention_backward takes at the default knobs: the fused window passes up to d = 64
+    (beyond, the two-row gathers dominate and they measure slower than the unfused passes); the
+    chunk-driver form only where the unfused passes would not run on the window drivers either."""
+    g = graphs.chung_lu_graph(30000, 3000000, alpha=0.5, seed=1, device=dev)      # 7.7 MB tables at d = 64: windows
+    for d, want in ((64, True), (128, False), (256, False)):
+        Q = torch.zeros(30000, d, device=dev)
+        assert ops.attention_backward_is_fused(*g.csr_args(), Q, Q) == want, d
+    q, k, v = (torch.rand(30000, 128, device=dev).requires_grad_(True) for _ in range(3))
+    o = functions.fused_attention_step(g, q, k, v, torch.rand(30000, 128, device=dev))     # keeps a, unfused backward
+    q2, k2, v2 = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    assert o.shape == (30000, 128) and q.grad is not None
 
 
 def test_fused_chunk_driver_cost_rule(dev):
@@ -297,7 +313,8 @@ def test_fused_fuzz_shapes_and_paths(dev, seed):
         knobs = dict(sweep_min_kb=0, sweep_min_granule=0, max_windows=512, window_kb=int(rng.choice([1, 4, 16])),
                      vrow_t=int(rng.choice([0, 64, 256])), attn_window_scale=int(rng.choice([1, 2, 4])),
                      attn_k=int(rng.choice([0, 1, 2, 4])), attn_bpc=int(rng.choice([0, 1, 2])),
-                     touch_sddmm=int(rng.choice([0, 1, 3])))
+                     touch_sddmm=int(rng.choice([0, 1, 3])), attn_max_d=int(rng.choice([64, 1024, 1024])),
+                     staged_ids=int(rng.choice([0, 7, 7])))
     for k, v in knobs.items():
         _lib.tune(k, v)
     _lib.clear_plan_cache()
@@ -316,6 +333,6 @@ def test_fused_fuzz_shapes_and_paths(dev, seed):
             close(got[key], want[key], rtol=2e-4, atol=2e-5)
     finally:
         for k, v in dict(sweep_min_kb=4608, sweep_min_granule=4, max_windows=128, window_kb=4096, vrow_t=0,
-                         attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1).items():
+                         attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1, attn_max_d=64, staged_ids=7).items():
             _lib.tune(k, v)
         _lib.clear_plan_cache()
