@@ -314,8 +314,8 @@ inline bool table_off32(i64 n_table_rows, int L, int NV) { return n_table_rows *
 inline bool sddmm_staged(const graphop_plan* plan, int L, int NV, i64 h, i64 n_table_rows) {
   return (tuning().staged_ids & 1) && h == 1 && plan->info.eid_identity && table_off32(n_table_rows, L, NV);
 }
-inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {   // 64-lane groups (d >= 256) would spill with the staging registers
-  return L <= 32 && (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
+inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
+  return (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
 }
 
 template <int L, int NV>
@@ -396,7 +396,7 @@ int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   SweepOpts so;
   so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
   const bool off32 = table_off32(n_table_rows, L, NV);
-  constexpr bool kStagedOk = L <= 32;
+  constexpr bool kStagedOk = true;
   so.staged = spmm_staged(L, NV, h, n_table_rows);
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &so);
   if (use != 1) return use;

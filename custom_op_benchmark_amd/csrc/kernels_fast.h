@@ -1321,8 +1321,10 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_spmm_wo
 }
 
 // Staged form (h == 1, table < 4 GiB, dealt layout in the view).
+// 64-lane groups (d >= 256) are compiled for 3 resident workgroups per CU (the launch default): the
+// staging registers do not fit the 128 VGPRs that 4 per CU leave.
 template <int L, int NV, bool EID_ID>
-__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, true, true)) void k_spmm_wown_staged_f32(
+__global__ __launch_bounds__(kFastBlock, L == 64 ? 3 : sweep_bpc(NV, true, true)) void k_spmm_wown_staged_f32(
     SweepView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
   extern __shared__ float4 lds[];
   constexpr int GW = kWave / L;

@@ -417,7 +417,7 @@ def test_id_staging_on_and_off_vs_oracle(dev, force_sweep, d, staged):
         _lib.profile_enable(False)
         if staged:
             assert "k_sddmm_wown_staged_f32" in kernels, kernels
-            assert d > 128 or "k_spmm_wown_staged_f32" in kernels, kernels
+            assert "k_spmm_wown_staged_f32" in kernels, kernels
         else:
             assert {"k_sddmm_wown_f32", "k_spmm_wown_f32"} <= kernels, kernels
     finally:
