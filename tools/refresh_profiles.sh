@@ -33,6 +33,11 @@ python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 >
 # input variants of the headline workload: worst-case locality, signed values
 python bench.py --alpha 0 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_alpha0_bench.json" 2>/dev/null
 python bench.py --values normal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_normal_bench.json" 2>/dev/null
+# the same graph at other row widths / head counts (not BASELINE configs: how far the headline tuning carries)
+for cfg in "128 1" "256 1" "16 4" "32 8"; do
+  set -- $cfg
+  python bench.py --graph reddit --d $1 --heads $2 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_h$2_d$1_bench.json" 2>/dev/null
+done
 echo "[refresh] variants done"
 python bench.py --graph harness --d 1024 --heads 1 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_d1024_bench.json" 2>/dev/null
 python bench.py --graph harness --d 64 --heads 8 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_harness_8x64_bench.json" 2>/dev/null
