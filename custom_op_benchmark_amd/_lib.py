@@ -313,6 +313,18 @@ def _hip_runtime():
 # so equal views of the same arrays share a plan.
 _plan_cache = collections.OrderedDict()
 _PLAN_CACHE_MAX = 64
+# ... and by bytes: plans with their window structures and window-major id copies hold 40-45 B per
+# edge (Reddit-shape: 4.9 GB for both orientations), so the cache also evicts least-recently-used
+# graphs while plan memory exceeds this many bytes (GRAPHOP_PLAN_CACHE_GB, default 96 of the 288 GB).
+_PLAN_CACHE_BYTES = int(float(os.environ.get("GRAPHOP_PLAN_CACHE_GB", "96")) * 2**30)
+
+
+def _evict_lru():
+    """Drop the least recently used graph from both cache levels (its plans are destroyed once no
+    op holds them; the next op on that graph rebuilds them)."""
+    _, ent = _plan_cache.popitem(last=False)
+    for p in ent.values():
+        p.tensors[0].__dict__.pop("_graphop_plans", None)
 
 
 def _key(*ts):
@@ -345,8 +357,8 @@ def get_plan(row, indptr, eid, indices=None, n_index_bound=0, state=None):
     k3 = _key(row, indptr, eid)
     entry = _plan_cache.get(k3)
     if entry is None:
-        while len(_plan_cache) >= _PLAN_CACHE_MAX:
-            _plan_cache.popitem(last=False)          # least recently used
+        while _plan_cache and (len(_plan_cache) >= _PLAN_CACHE_MAX or plan_memory_bytes() > _PLAN_CACHE_BYTES):
+            _evict_lru()
         entry = _plan_cache[k3] = {}
     else:
         _plan_cache.move_to_end(k3)

@@ -73,6 +73,34 @@ def test_prepare_covers_the_whole_step_and_release_frees(dev, small_windows):
     assert _lib.plan_memory_bytes() <= base
 
 
+def test_plan_cache_is_capped_by_bytes(dev):
+    """The cache also evicts least-recently-used graphs while plan memory exceeds its byte budget
+    (GRAPHOP_PLAN_CACHE_GB): the evicted graph's plans are destroyed, their memory returns to torch."""
+    import gc
+    _lib.clear_plan_cache(); gc.collect()
+    base = _lib.plan_memory_bytes()
+    gs = [graphs.uniform_random_graph(3000, 60000, seed=s).to(dev) for s in range(3)]
+    old = _lib._PLAN_CACHE_BYTES
+    try:
+        _lib.get_plan(gs[0].row, gs[0].ptr_r, gs[0].eid_r, gs[0].indices_r, 3000)
+        one = _lib.plan_memory_bytes() - base
+        assert one > 0
+        _lib._PLAN_CACHE_BYTES = base + one // 2          # less than one graph's plans
+        for g in gs[1:]:
+            _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, 3000)
+            gc.collect()
+            assert len(_lib._plan_cache) == 1                                    # the previous graph went
+            assert _lib.plan_memory_bytes() - base <= one + one // 4             # and so did its memory
+        assert "_graphop_plans" not in gs[0].row.__dict__ and "_graphop_plans" in gs[2].row.__dict__
+        # an evicted graph still works: its plan is rebuilt on the next use
+        A = torch.rand(3000, 16, device=dev)
+        y = ops.maskedmm_csr_forward(gs[0].row, gs[0].ptr_r, gs[0].eid_r, gs[0].indices_r, A, A)
+        assert torch.isfinite(y).all()
+    finally:
+        _lib._PLAN_CACHE_BYTES = old
+        _lib.clear_plan_cache()
+
+
 def test_plan_cache_is_lru(dev):
     _lib.clear_plan_cache()
     gs = [graphs.uniform_random_graph(20, 100, seed=s).to(dev) for s in range(3)]
