@@ -68,7 +68,7 @@ struct PlanEntry {
 std::mutex g_mu;
 std::unordered_map<PlanKey, PlanEntry, PlanKeyHash> g_plans;
 std::list<PlanKey> g_lru;
-constexpr size_t kMaxPlans = 64;
+constexpr size_t kMaxPlans = 16;   // a Reddit-size graph's plans hold ~5 GB (window structures + window-major id copies)
 
 const PlanEntry& get_plan(const at::Tensor& row, const at::Tensor& indptr, const at::Tensor& eid,
                           const at::Tensor& indices, int64_t bound) {
