@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -50,6 +50,7 @@ class ProfileRec(ctypes.Structure):
 _P = _vp
 _SIGNATURES = {
     "graphop_tune": [ctypes.c_char_p, ctypes.c_int],
+    "graphop_tune_reset": [],
     "graphop_profile_enable": [ctypes.c_int],
     "graphop_profile_read": [ctypes.POINTER(ProfileRec), ctypes.c_int],
     "graphop_partition_csr_count": [_P, _c64, _c64, _P, _P],
@@ -392,6 +393,11 @@ def release_plans(*rows):
 def tune(key, value):
     """Set a tuning knob (include/graphop_hip.h: graphop_tune)."""
     check(lib().graphop_tune(key.encode(), int(value)))
+
+
+def tune_reset():
+    """Every knob back to its default (include/graphop_hip.h: graphop_tune_reset)."""
+    check(lib().graphop_tune_reset())
 
 
 def profile_enable(on=True):

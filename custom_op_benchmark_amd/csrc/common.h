@@ -104,6 +104,35 @@ struct Sweep {
   Dealt dealt[kMaxDealt];
   int n_dealt = 0;
 };
+// Walk layout of one plan (kernels_walk.h): the slots of the CSR, read as one tape, are cut into
+// waves * rounds BINS of equal length; bin (round r, wave q) is what wave q of the resident grid
+// works on in round r.  A bin holds at most kWalkK * GW rows (whole rows, plus the pieces of the rows
+// its two ends cut; a piece takes its share of the row's slots inside EVERY column window).  Inside
+// every window the bin's slots are dealt to the wave's GW lane groups in equal contiguous shares; a
+// lane group's shares of windows 0, 1, ... are stored as ONE contiguous run: per slot the neighbour
+// id with the bin-local row number in the top bits, and the edge id (index of the per-edge scalar /
+// result).  A lane group streams its run through LDS; the wave keeps the bin's rows (partial sums of
+// an SpMM-type pass, A rows of an SDDMM-type pass) in LDS for the whole round: nothing is flushed
+// per window.
+struct Walk {
+  int W = 0;
+  i64 win_cols = 0;
+  int groups = 0;         // lane groups of the resident grid the tape was cut for
+  int GW = 0;             // lane groups per wave
+  int rounds = 0;
+  int xcd_slots = 0;      // 8 (groups % 8 == 0: every XCD slot owns a contiguous share of each round's tape) or 1
+  long long n_slots = 0;  // ints in ids / widx (bins padded to 4, slack for whole-segment fetches)
+  int* ids = nullptr;     // [(k << kWalkKShift) | neighbour id]
+  int* widx = nullptr;    // edge id per slot
+  int* bin_pos = nullptr; // [bins * GW + 1] first slot of every lane group's run
+  int* bin_rows = nullptr;// [bins * kWalkK * GW] row id | (shared << 31), -1 = unused
+  int* bin_cum = nullptr; // [bins * GW] slots in every lane group's run
+  int* sync = nullptr;    // pacer counters of the walk kernels (zeroed before every launch)
+  long long sync_ints = 0;
+  int max_steps = 0;      // pacing steps per round the counters are sized for
+};
+constexpr int kWalkK = 14;        // rows per lane group: 14 x 256 B x 16 lane groups + the id rings = 2 workgroups per CU
+constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)
 constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
@@ -118,6 +147,7 @@ struct graphop_plan {
   int sorted_in_rows;      // neighbour ids ascend inside every row segment
   void* sweeps;            // std::vector<graphop::Sweep>* (lazily built, guarded by sweep_mu)
   void* sweep_mu;          // std::mutex*
+  void* walks;             // std::vector<graphop::Walk>* (lazily built, guarded by sweep_mu)
   const int64_t* row;      // identity of the arrays the plan was built from (not owned)
   const int64_t* indptr;
   const int64_t* eid;

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "host.h"
 #include "kernels_fast.h"
+#include "kernels_walk.h"
 #include "kernels_block.h"
 #include "kernels_attn.h"
 #include "kernels_generic.h"
@@ -107,6 +108,7 @@ int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Swe
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
+int plan_get_walk(graphop_plan*, int, i64, int, int, int, hipStream_t, const Walk**);
 
 Tuning& tuning_mut() {
   static Tuning t;
@@ -318,6 +320,157 @@ inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
   return (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
 }
 
+// ---- walk drivers (kernels_walk.h) -----------------------------------------------------------------
+struct WalkLaunch {
+  WalkView view;
+  unsigned blocks;
+  size_t lds_bytes;
+};
+
+// Diagnostics (knob walk_debug): per-wave cycle counts of one walk launch, summarised on stderr.
+struct WalkDebug {
+  long long* buf = nullptr;
+  unsigned blocks = 0;
+  const char* tag = "";
+  hipStream_t st = nullptr;
+  int rounds = 0, W = 0;
+  void arm(WalkLaunch* wl, const char* t, hipStream_t s) {
+    if (!tuning().walk_debug) return;
+    blocks = wl->blocks; tag = t; st = s; rounds = wl->view.rounds; W = wl->view.steps;
+    if (hipMalloc((void**)&buf, sizeof(long long) * 16 * blocks) != hipSuccess) { buf = nullptr; return; }
+    (void)hipMemsetAsync(buf, 0, sizeof(long long) * 16 * blocks, s);
+    wl->view.dbg = buf;
+  }
+  ~WalkDebug() {
+    if (!buf) return;
+    std::vector<long long> h((size_t)16 * blocks);
+    if (hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(h.data(), buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      double tot = 0, wait = 0, nw = 0; long long tmax = 0, tmin = 1LL << 62; int gave = 0;
+      double xt[8] = {0}, xw[8] = {0}; int xn[8] = {0};
+      const size_t n = (size_t)4 * blocks;
+      for (size_t i = 0; i < n; ++i) {
+        const long long* d = &h[i * 4];
+        tot += d[0]; wait += d[1]; nw += d[2];
+        tmax = d[0] > tmax ? d[0] : tmax; tmin = d[0] < tmin ? d[0] : tmin;
+        gave += (d[3] & 16) ? 1 : 0;
+        const int x = (int)(d[3] & 7); xt[x] += d[0]; xw[x] += d[1]; xn[x]++;
+      }
+      fprintf(stderr, "[walk] %s rounds=%d steps=%d waves=%zu cycles mean %.0f min %lld max %lld | pacer wait %.1f %% of wave time, %.1f waits/wave, %d gave up | per XCD wait%%:",
+              tag, rounds, W, n, tot / n, tmin, tmax, 100.0 * wait / (tot > 0 ? tot : 1), nw / n, gave);
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f(%d)", xn[x] ? 100.0 * xw[x] / (xt[x] > 0 ? xt[x] : 1) : 0.0, xn[x]);
+      fprintf(stderr, "\n");
+    }
+    (void)hipFree(buf);
+  }
+};
+
+// Decide whether the walk drivers apply to a pass over `plan` that gathers rows of 16*L*NV bytes from a
+// table of n_table_rows rows, and fetch / build the layout.  1 = use it, 0 = no, < 0 = error (negated).
+template <int L, int NV>
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
+  if constexpr (NV != 1 || L < 16) {
+    return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
+  } else {
+    const Tuning& t = tuning();
+    if (!plan) return 0;
+    const graphop_plan_info_t& pi = plan->info;
+    if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
+    if (!pi.eid_identity && !plan->eid32) return 0;
+    if (pi.n_segments == 0 || pi.n_edges == 0 || !table_off32(n_table_rows, L, NV)) return 0;
+    if (pi.max_index >= (1LL << kWalkKShift)) return 0;
+    const i64 table_bytes = n_table_rows * 16LL * L * NV;
+    if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
+    i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes, (i64)t.walk_window_kb * 1024));
+    if (W < 2) W = 2;
+    if (W > t.max_windows || W > 512) return 0;
+    const i64 mean_row = pi.n_edges / pi.n_segments;
+    if (mean_row < (i64)t.sweep_min_granule * W / 2) return 0;
+    constexpr int GPB = kFastBlock / L;
+    i64 blocks = t.walk_blocks > 0 ? t.walk_blocks : (i64)t.n_cu * kWalkBpc;
+    int slots = 8;
+    if (blocks >= 8) blocks -= blocks % 8; else slots = 1;
+    const i64 groups = blocks * GPB;
+    if (pi.n_edges < groups * (i64)t.walk_min_bin) return 0;
+    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc, "two walk workgroups per CU");
+    const Walk* wk = nullptr;
+    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, kWave / L,
+                                 slots, st, &wk);
+    if (rc != GRAPHOP_OK) return -rc;
+    if (!wk) return 0;
+    out->view.ids = wk->ids; out->view.widx = wk->widx; out->view.bin_pos = wk->bin_pos;
+    out->view.bin_rows = wk->bin_rows; out->view.bin_cum = wk->bin_cum;
+    out->view.W = wk->W; out->view.groups = wk->groups; out->view.rounds = wk->rounds;
+    out->view.xcd_slots = slots;
+    // pacing steps: equal slot counts; every bin holds n_edges / bins slots, give or take one per window
+    {
+      constexpr int SB = StripCfg<L, NV>::SB;
+      const i64 runs = (i64)wk->groups * wk->rounds;   // one per lane group and round
+      const i64 longest = ceil_div(pi.n_edges, runs) + 2 * wk->W + 1;
+      i64 steps = (i64)wk->W * (t.walk_steps > 0 ? t.walk_steps : 1);
+      if (steps > wk->max_steps) steps = wk->max_steps;
+      if (steps < 1) steps = 1;
+      out->view.steps = (int)steps;
+      out->view.step_len = (int)(ceil_div(ceil_div(longest, steps), 2 * SB) * 2 * SB);   // (the kernels check every second batch)
+    }
+    out->view.drift = t.walk_drift;
+    out->view.sync = t.walk_drift > 0 ? wk->sync : nullptr;
+    out->view.dbg = nullptr;
+    out->view.experiment = env_int("GRAPHOP_WALK_EXPERIMENT", 0);
+    out->blocks = (unsigned)blocks;
+    out->lds_bytes = walk_lds_bytes<L, NV>();
+    if (!dry_run && out->view.sync &&
+        zero_async(out->view.sync, sizeof(int) * 64 * (size_t)(8 + 16 * (i64)wk->rounds * out->view.steps), st) != hipSuccess)
+      return -GRAPHOP_ERR_HIP;
+    return 1;
+  }
+}
+
+template <int L, int NV>
+int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A, const void* B,
+                   void* y, i64 h, hipStream_t st) {
+  if constexpr (NV != 1 || L < 16) {
+    return 0;
+  } else {
+    if (!(tuning().walk & 1) || h != 1 || !plan) return 0;
+    WalkLaunch wl;
+    const int use = choose_walk<L, NV>(plan, n_table_rows, st, &wl);
+    if (use != 1) return use;
+    static const bool attr = hipFuncSetAttribute((const void*)k_sddmm_walk_f32<L, NV>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
+    (void)attr;
+    WalkDebug dbg;
+    dbg.arm(&wl, tag, st);
+    ProfScope prof(tag, st, "k_sddmm_walk_f32");
+    hipLaunchKernelGGL((k_sddmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kFastBlock), wl.lds_bytes, st, wl.view,
+                       (const float*)A, (const float*)B, (float*)y);
+    return 1;
+  }
+}
+
+template <int L, int NV>
+int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w, const void* X,
+                  void* out, i64 h, hipStream_t st) {
+  if constexpr (NV != 1 || L < 16) {
+    return 0;
+  } else {
+    if (h != 1 || !plan) return 0;
+    if (!(tuning().walk & (plan->info.eid_identity ? 2 : 4))) return 0;
+    WalkLaunch wl;
+    const int use = choose_walk<L, NV>(plan, n_table_rows, st, &wl);
+    if (use != 1) return use;
+    static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
+    (void)attr;
+    WalkDebug dbg;
+    dbg.arm(&wl, tag, st);
+    ProfScope prof(tag, st, "k_spmm_walk_f32");
+    hipLaunchKernelGGL((k_spmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kFastBlock), wl.lds_bytes, st, wl.view,
+                       (const float*)w, (const float*)X, (float*)out);
+    return 1;
+  }
+}
+
 template <int L, int NV>
 int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
                     const void* B, void* y, i64 h, int d4, hipStream_t st) {
@@ -523,6 +676,9 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
     const int F = (int)(h * d), d4 = (int)(d / 4);
     if constexpr (!EDGE_B) {
       int use = 0;
+      GO_DISPATCH_LNV(F, { use = try_sddmm_walk<L, NV>(tag, plan, n_src_rows, A, B, y, h, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
       GO_DISPATCH_LNV(F, { use = try_sddmm_sweep<L, NV>(tag, plan, n_src_rows, A, B, y, h, d4, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
@@ -571,6 +727,9 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
     const int F = (int)(h * d), d4 = (int)(d / 4);
     {
       int use = 0;
+      GO_DISPATCH_LNV(F, { use = try_spmm_walk<L, NV>(tag, plan, n_src_rows, w, X, out, h, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
       GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, other, n_other_cols, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
@@ -786,7 +945,8 @@ int graphop_tune(const char* key, int value) {
       {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
       {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
-      {"touch_sddmm", &t.touch_sddmm}};
+      {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb},
+      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
@@ -794,6 +954,11 @@ int graphop_tune(const char* key, int value) {
     }
   set_error("tune: unknown key '%s'", key);
   return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
+int graphop_tune_reset(void) {
+  tuning_mut() = Tuning();   // the defaults (environment overrides included), as at library load
+  return GRAPHOP_OK;
 }
 
 int graphop_set_allocator(graphop_alloc_fn alloc_fn, graphop_free_fn free_fn) {

@@ -48,6 +48,14 @@ struct Tuning {
                           // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
+  int walk;               // walk drivers (kernels_walk.h): bit 0 SDDMM-type passes, bit 1 SpMM-type over identity-eid
+                          // (row-major) slots, bit 2 SpMM-type over permuted (column-major) slots
+  int walk_window_kb;     // bytes of gathered table per window of the walk drivers (two windows live in a 4 MiB L2)
+  int walk_drift;         // pacing steps a wave may run ahead of the slowest wave of its XCD (0 = free-running)
+  int walk_steps;         // pacing steps per column window
+  int walk_min_bin;       // fewest slots per (lane group, round) bin for the walk drivers to be chosen
+  int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
+  int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -76,6 +84,13 @@ struct Tuning {
     attn_max_d = env_int("GRAPHOP_ATTN_MAX_D", 64);
     staged_ids = env_int("GRAPHOP_STAGED_IDS", 7);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
+    walk = env_int("GRAPHOP_WALK", 7);
+    walk_window_kb = env_int("GRAPHOP_WALK_WINDOW_KB", 2048);
+    walk_drift = env_int("GRAPHOP_WALK_DRIFT", 2);
+    walk_steps = env_int("GRAPHOP_WALK_STEPS", 2);
+    walk_min_bin = env_int("GRAPHOP_WALK_MIN_BIN", 1024);
+    walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
+    walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;

@@ -1,0 +1,404 @@
+// WALK drivers (plan; common.h: Walk): the flush-free loop order of the column-window passes.
+//
+// The window-owner drivers (kernels_fast.h) let every XCD own column windows; a row's partial sum
+// then leaves the chip once per (row, window) -- memory-side float atomics, 1-1.4 GB per pass on
+// the Reddit shape -- and the A rows of an SDDMM-type pass are re-read per (row, window).  Here the
+// ownership is turned around: a WAVE owns a BIN of rows for a whole round (plan.hip cuts the CSR,
+// read as one tape of slots, into waves x rounds bins of equal length) and keeps them in LDS --
+// partial sums of an SpMM-type pass, A rows of an SDDMM-type pass -- while it walks ALL column
+// windows, window 0 first.  All waves of the chip therefore gather from the same part of the table
+// at about the same time, which keeps that part in every XCD's L2; a per-XCD soft pacer
+// (WalkPacer) bounds how far a wave may run ahead.  Nothing is flushed per window: a row is written
+// once per round (plain stores; atomics only for the <= 2 rows a bin shares with its neighbours).
+//
+// Inside every window the bin's slots are dealt to the wave's lane groups in equal contiguous
+// shares, and a lane group's shares of all windows are one contiguous run of (row-in-bin |
+// neighbour id, edge id) pairs streamed through the group's LDS ring (IdStage, two streams): a
+// strip is ONE flat list of full 16-slot batches for the whole round -- no per-window round-up, no
+// dealing -- and the groups of a wave, which run in lock step, are always in the same window.
+// Where a bin stands in the table after a given share of its slots varies from bin to bin like
+// 1 / sqrt(slots per bin) (which windows a row's neighbours fall into is random): bins per wave
+// rather than per lane group halve that spread, which is what the L2 has to hold.
+// The lane groups of a wave share the bin's LDS rows: a row whose slots of one window are cut
+// between two groups is updated by both, so the read-modify-write of a partial sum is issued one
+// lane group at a time (LDS operations of one wave execute in order).
+#pragma once
+#include "kernels_fast.h"
+
+namespace graphop {
+
+struct WalkView {
+  const int* ids;        // [(k << kWalkKShift) | neighbour id] per slot
+  const int* widx;       // edge id per slot
+  const int* bin_pos;    // [bins * GW + 1] first slot of every lane group's run
+  const int* bin_rows;   // [bins * kWalkK * GW]
+  const int* bin_cum;    // [bins * GW] slots in every lane group's run
+  int* sync;             // pacer counters, zero at launch (nullptr = free-running)
+  int W, groups, rounds;
+  int steps;             // pacing steps per round: step = (first slot of the batch) / step_len, the same for every bin
+  int step_len;          // slots per pacing step (multiple of the batch size; steps * step_len >= the longest bin)
+  int drift;             // a wave may start step s only once every wave of its XCD has left step s - drift
+  int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
+  int experiment;        // measurement variants (WRONG RESULTS): bit 0 every gather inside one 2 MB region, bit 1 no weight loads / result stores
+  long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
+};
+
+constexpr int kWalkIdMask = (1 << kWalkKShift) - 1;
+constexpr int kWalkBpc = 2;   // resident workgroups per CU the walk kernels are sized for (LDS)
+
+// Soft pacing between the waves of one walk launch, per XCD (counters sharded by the hardware XCC id,
+// layout as SweepPacer: sync[xcc * 64] = workgroups registered, then per (XCD, step) an arrival
+// counter and a release word, one 256-B line each).  A wave SIGNALS the steps all of its lane groups
+// have left and, before it gathers from step s, WAITS until every registered workgroup of its XCD
+// has left step s - drift -- unless one of its own groups is still that far back (it cannot wait for
+// itself; the slowest wave of an XCD never waits, so there is always progress).  Speed only: spins
+// are bounded and a wave that times out stops pacing for good.
+struct WalkPacer {
+  int* ctr;
+  int* reg;
+  int* lds;        // [0..7] waves of this workgroup done with step (s & 7); [8] highest released step + 1
+  int drift;
+  int done_next;   // first step this wave has not signalled yet (wave-uniform)
+  bool active;
+  long long t_wait = 0, n_wait = 0;   // diagnostics
+  static constexpr int kWaves = kFastBlock / kWave;
+  __device__ __forceinline__ WalkPacer(const WalkView& s, int* lds_words)
+      : ctr(nullptr), reg(nullptr), lds(lds_words), drift(s.drift), done_next(0),
+        active(s.sync != nullptr && s.drift > 0) {
+    if (!active) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= kSyncXcds - 1;
+    const i64 steps = (i64)s.rounds * s.steps;
+    reg = s.sync + (i64)xcc * kSyncStride;
+    ctr = s.sync + (i64)kSyncStride * (kSyncXcds + 2 * (i64)xcc * steps);
+    if (threadIdx.x < 9) lds[threadIdx.x] = 0;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  // every lane group of this wave has left all steps < upto (wave-uniform call, all lanes)
+  __device__ __forceinline__ void signal_upto(int upto) {
+    if (upto <= done_next) return;
+    if (active && (threadIdx.x & (kWave - 1)) == 0) {
+      for (int st = done_next; st < upto; ++st) {
+        int* slot = lds + (st & 7);
+        const int old = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == kWaves - 1) {            // last wave of this workgroup for step st
+          __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          int* c = ctr + (i64)st * 2 * kSyncStride;
+          const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (prev + 1 >= n) __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    done_next = upto;
+  }
+  // about to gather from `step`; own_min = the step the slowest lane group of this wave is in
+  __device__ __forceinline__ void wait_enter(int step, int own_min) {
+    const int need = step - drift;
+    if (!active || need < 0 || own_min <= need) return;
+    int gave_up = 0;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & (kWave - 1)) == 0 &&
+        __hip_atomic_load(lds + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= need) {
+      const int* rel = ctr + ((i64)need * 2 + 1) * kSyncStride;
+      int it = 0;
+      while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++it > 3000) { gave_up = 1; break; }   // ~2 ms without progress: give up pacing for good
+      }
+      if (!gave_up) __hip_atomic_fetch_max(lds + 8, need + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (__shfl(gave_up, 0)) active = false;
+    t_wait += __builtin_amdgcn_s_memtime() - t0;
+    n_wait += 1;
+  }
+  __device__ __forceinline__ void report(long long* dbg, long long t_start) const {
+    if (dbg && (threadIdx.x & (kWave - 1)) == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      long long* d = dbg + ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 4;
+      d[0] = __builtin_amdgcn_s_memtime() - t_start; d[1] = t_wait; d[2] = n_wait; d[3] = (active ? 0 : 16) + (xcc & 7);
+    }
+  }
+};
+
+template <int L>
+__device__ __forceinline__ i64 walk_bin_index(const WalkView& s, int r) {   // this wave's bin in round r
+  constexpr int WPB = kFastBlock / kWave, GW = kWave / L;
+  const int slots = s.xcd_slots;
+  const i64 x = blockIdx.x % slots, i = blockIdx.x / slots;
+  const i64 per_slot = (s.groups / GW) / slots;            // waves per XCD slot
+  return ((i64)r * slots + x) * per_slot + i * WPB + (threadIdx.x >> 6);
+}
+
+template <int L>
+__device__ __forceinline__ int wave_max_int(int v) {   // v group-uniform
+  if constexpr (kWave / L == 1) return v;
+  int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+  for (int g = 1; g < kWave / L; ++g) {
+    const int o = __builtin_amdgcn_readlane(v, g * L);
+    m = o > m ? o : m;
+  }
+  return m;
+}
+
+// LDS of one workgroup: [waves][kWalkK * GW] rows of 16*L*NV bytes, then the id rings.
+template <int L, int NV>
+__host__ __device__ constexpr size_t walk_lds_bytes() {
+  return (size_t)(kFastBlock / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)StageCfg<L, 2>::kLdsIntsPerGroup * 4);
+}
+
+// Both kernels keep TWO batches of rows in flight per lane group (the 256-VGPR budget of two waves per
+// SIMD pays for the second buffer): the row requests of batch b + 1 are issued before batch b is
+// consumed, so a wave always has 16 KB of gathers outstanding while it reduces / accumulates.
+
+// out[row] = sum over the row's slots of w[edge] * X[neighbour]   (graphop_kernel.cu:100-112, :118-130, :151-163)
+template <int L, int NV>
+__global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
+    WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
+  extern __shared__ float4 lds[];
+  constexpr int GPB = kFastBlock / L, GW = kWave / L, KW = kWalkK * GW;
+  constexpr i64 F4 = (i64)L * NV;
+  constexpr int SB = StripCfg<L, NV>::SB;
+  static_assert(L >= 16 && KW <= kWave && KW <= (1 << (32 - kWalkKShift)), "lane k of a wave holds the bin's k-th row");
+  const int l = threadIdx.x % L;
+  const int g_in_blk = threadIdx.x / L;
+  const int gq = g_in_blk % GW;                      // lane group inside the wave
+  const int lw = threadIdx.x & (kWave - 1);
+  float4* accs = lds + (i64)(threadIdx.x >> 6) * KW * F4;   // [KW][NV][L], shared by the wave's lane groups
+  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4) + g_in_blk * StageCfg<L, 2>::kLdsIntsPerGroup;
+  __shared__ int pace_words[16];
+  const long long t_start = __builtin_amdgcn_s_memtime();
+  WalkPacer pacer(s, pace_words);
+  for (int r = 0; r < s.rounds; ++r) {
+    const i64 tb = walk_bin_index<L>(s, r);
+    const i64 gb = tb * GW + gq;
+    const int pos0 = s.bin_pos[gb];
+    const int total = s.bin_cum[gb];
+    const int my_row = lw < KW ? s.bin_rows[tb * KW + lw] : -1;
+    int next_step_at = 0;
+    for (int k = gq; k < KW; k += GW)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wave_total = wave_max_int<L>(total);
+    IdStage<L, 2> ids;
+    if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k_cur = -1;
+    auto rmw = [&]() {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float4 o = accs[(k_cur * NV + v) * L + l];
+        o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+        accs[(k_cur * NV + v) * L + l] = o;
+      }
+    };
+    // Partial sum of the row k_cur -> its LDS row.  The lane groups of a wave share the rows, and a row
+    // whose slots of one window are cut between two groups is held by both: when two of the groups
+    // that spill at this point hold the SAME row, the updates are issued one group at a time (LDS
+    // operations of one wave execute in order); otherwise all of them at once.
+    auto spill = [&]() {
+      if (k_cur >= 0) {
+        bool clash = false;
+        if constexpr (GW > 1) {
+          const unsigned long long act = __ballot(1);
+          int kq[GW];
+#pragma unroll
+          for (int q = 0; q < GW; ++q) kq[q] = ((act >> (q * L)) & 1) ? __builtin_amdgcn_readlane(k_cur, q * L) : -1 - q;
+#pragma unroll
+          for (int q = 0; q < GW; ++q)
+#pragma unroll
+            for (int p = q + 1; p < GW; ++p) clash |= kq[q] == kq[p];
+        }
+        if (!clash) {
+          rmw();
+        } else {
+#pragma unroll
+          for (int q = 0; q < GW; ++q) {
+            // (q is made opaque: to one thread the GW guarded copies are mutually exclusive and would
+            // be merged back into a single unguarded update)
+            int qq = q;
+            asm volatile("" : "+s"(qq) : : "memory");
+            if (gq == qq) rmw();
+            asm volatile("" ::: "memory");
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    struct Meta { int k; float w; };
+    auto issue = [&](int jb, float4 (&x)[SB][NV], Meta& m) {   // ids + weight of batch jb, then its row requests
+      ids.advance(jb);
+      const int jj = jb + l;
+      const bool live = l < SB && jj < total;
+      const int j = jj < total ? jj : total - 1;   // slots past the end re-read the last neighbour with weight 0
+      const int idw = ids.id(j);
+      m.k = (int)((unsigned)idw >> kWalkKShift);
+      const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
+      m.w = 0.f;
+      if (live) m.w = (s.experiment & 2) ? 1.f : wgt[ids.eid(j)];
+      static_for<SB>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const unsigned o = group_bcast<L, u>(my_off);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
+      });
+    };
+    auto consume = [&](const float4 (&x)[SB][NV], const Meta& m) {
+      static_for<SB>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int kt = group_bcast<L, u>(m.k);
+        if (kt != k_cur) {   // group-uniform
+          spill();
+          k_cur = kt;
+        }
+        const float w1 = group_bcast<L, u>(m.w);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          acc[v].x = fmaf(w1, x[u][v].x, acc[v].x);
+          acc[v].y = fmaf(w1, x[u][v].y, acc[v].y);
+          acc[v].z = fmaf(w1, x[u][v].z, acc[v].z);
+          acc[v].w = fmaf(w1, x[u][v].w, acc[v].w);
+        }
+      });
+    };
+    float4 xa[SB][NV], xb[SB][NV];
+    Meta ma, mb;
+    ma.k = mb.k = 0; ma.w = mb.w = 0.f;
+    if (total > 0) issue(0, xa, ma);
+    for (int jb = 0; jb < wave_total; jb += 2 * SB) {
+      // pacing by progress: the lane groups of a wave hold equal shares of every window, and all bins
+      // hold the same number of slots (+- W), so equal positions in their runs mean nearly equal columns
+      if (jb >= next_step_at) {   // wave-uniform
+        const int step = r * s.steps + jb / s.step_len;
+        pacer.signal_upto(step);
+        pacer.wait_enter(step, step);
+        next_step_at = (jb / s.step_len + 1) * s.step_len;
+      }
+      if (jb + SB < total) issue(jb + SB, xb, mb);
+      if (jb < total) consume(xa, ma);
+      if (jb + 2 * SB < total) issue(jb + 2 * SB, xa, ma);
+      if (jb + SB < total) consume(xb, mb);
+    }
+    spill();
+    pacer.signal_upto((r + 1) * s.steps);
+    // the bin's rows leave the chip once: plain stores for rows that are wholly inside the bin, float
+    // atomics for the (at most two) rows it shares with its neighbours
+    for (int k = gq; k < KW; k += GW) {
+      const int rec = __shfl(my_row, k);
+      if (rec == -1) continue;   // group-uniform
+      const i64 row = rec & 0x7fffffff;
+      float4 a[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) a[v] = accs[(k * NV + v) * L + l];
+      if (rec < 0) {
+        atomic_flush_dense<L, NV>(out, row, a, l);
+      } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[row * F4 + v * L + l] = a[v];
+      }
+    }
+  }
+  pacer.report(s.dbg, t_start);
+}
+
+// y[edge] = <A[row], B[neighbour]>   (graphop_kernel.cu:40-55, :135-149); h == 1
+template <int L, int NV>
+__global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
+    WalkView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y) {
+  extern __shared__ float4 lds[];
+  constexpr int GPB = kFastBlock / L, GW = kWave / L, KW = kWalkK * GW;
+  constexpr i64 F4 = (i64)L * NV;
+  constexpr int SB = StripCfg<L, NV>::SB;
+  static_assert(L >= 16 && KW <= kWave && KW <= (1 << (32 - kWalkKShift)), "lane k of a wave holds the bin's k-th row");
+  const int l = threadIdx.x % L;
+  const int g_in_blk = threadIdx.x / L;
+  const int gq = g_in_blk % GW;
+  const int lw = threadIdx.x & (kWave - 1);
+  float4* rowsA = lds + (i64)(threadIdx.x >> 6) * KW * F4;   // [KW][NV][L], shared by the wave's lane groups
+  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4) + g_in_blk * StageCfg<L, 2>::kLdsIntsPerGroup;
+  __shared__ int pace_words[16];
+  const long long t_start = __builtin_amdgcn_s_memtime();
+  WalkPacer pacer(s, pace_words);
+  const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
+  for (int r = 0; r < s.rounds; ++r) {
+    const i64 tb = walk_bin_index<L>(s, r);
+    const i64 gb = tb * GW + gq;
+    const int pos0 = s.bin_pos[gb];
+    const int total = s.bin_cum[gb];
+    const int my_row = lw < KW ? s.bin_rows[tb * KW + lw] : -1;
+    int next_step_at = 0;
+    const int wave_total = wave_max_int<L>(total);
+    IdStage<L, 2> ids;
+    if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
+    for (int k = gq; k < KW; k += GW) {   // A rows of the bin -> LDS (behind the first id segment's request)
+      const int rec = __shfl(my_row, k);
+      if (rec == -1) continue;
+      const i64 row = rec & 0x7fffffff;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) rowsA[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
+    }
+    float prev_res = 0.f;
+    int prev_e = -1;
+    struct Meta { int e; unsigned koff; };
+    auto issue = [&](int jb, float4 (&b)[SB][NV], Meta& m) {
+      const int nb = (total - jb) < SB ? (total - jb) : SB;
+      ids.advance(jb);
+      const int j = (jb + l) < total ? jb + l : total - 1;   // lanes past the end re-read the last slot
+      const int idw = ids.id(j);
+      m.e = (l < nb) ? ids.eid(j) : -1;
+      m.koff = ((unsigned)idw >> kWalkKShift) * (unsigned)(F4 * 16);
+      const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
+      static_for<SB>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const unsigned o = group_bcast<L, u>(my_off);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
+      });
+    };
+    auto consume = [&](const float4 (&b)[SB][NV], const Meta& m) {
+      if (prev_e >= 0 && !(s.experiment & 2)) y[prev_e] = prev_res;   // behind the next batch's row requests
+      float part[SB];
+      static_for<SB>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const unsigned ko = group_bcast<L, u>(m.koff);
+        float4 av[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
+        float p = dot4(av[0], b[u][0]);
+#pragma unroll
+        for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
+        part[u] = p;
+      });
+      prev_res = group_dots_to_owner<L, SB>(part, l);
+      prev_e = m.e;
+    };
+    float4 ba[SB][NV], bb[SB][NV];
+    Meta ma, mb;
+    ma.e = mb.e = -1; ma.koff = mb.koff = 0;
+    if (total > 0) issue(0, ba, ma);
+    for (int jb = 0; jb < wave_total; jb += 2 * SB) {
+      if (jb >= next_step_at) {   // wave-uniform
+        const int step = r * s.steps + jb / s.step_len;
+        pacer.signal_upto(step);
+        pacer.wait_enter(step, step);
+        next_step_at = (jb / s.step_len + 1) * s.step_len;
+      }
+      if (jb + SB < total) issue(jb + SB, bb, mb);
+      if (jb < total) consume(ba, ma);
+      if (jb + 2 * SB < total) issue(jb + 2 * SB, ba, ma);
+      if (jb + SB < total) consume(bb, mb);
+    }
+    if (prev_e >= 0) y[prev_e] = prev_res;
+    pacer.signal_upto((r + 1) * s.steps);
+  }
+  pacer.report(s.dbg, t_start);
+}
+
+}  // namespace graphop

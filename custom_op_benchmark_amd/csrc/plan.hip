@@ -320,6 +320,135 @@ __global__ __launch_bounds__(256) void k_deal_fill(const int* __restrict__ strip
   }
 }
 
+// ---- walk layout (common.h: Walk; kernels_walk.h) ------------------------------------------------------
+// The tape = slots [e0, e0 + etot) of the CSR in storage order; bin tb (one per WAVE and round) takes
+// [t0, t1) = e0 + [tb, tb + 1) * etot / bins.  Rows (plan segments) s0 .. s1 intersect it; a row
+// [rs, re) of n slots contributes the piece [a, b) = [t0, t1) - rs clipped to [0, n), and INSIDE window
+// w -- the row's slots [lo_w, lo_w + n_w) there -- the slots lo_w + [a * n_w / n, b * n_w / n): the
+// pieces of a cut row tile each of its windows exactly (neighbouring bins compute the same quotient at
+// their seam).  The bin's slots of window w, rows in order, form one list of n_w slots; lane group g of
+// the wave takes its g-th GW-th, [g * n_w / GW, (g + 1) * n_w / GW): the groups of a wave hold equal
+// shares of EVERY window, so they leave a window together, and a group's run -- its shares of windows
+// 0, 1, ... one after the other -- is contiguous in memory.
+struct WalkBin {
+  int s0, nk;       // first segment, segments touched (clamped to kmax)
+  i64 t0, t1;
+};
+__device__ __forceinline__ i64 walk_upper(const i64* __restrict__ seg_eptr, i64 S, i64 t) {
+  i64 lo = 0, hi = S + 1;   // first index with seg_eptr[i] > t
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    if (seg_eptr[mid] <= t) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ WalkBin walk_bin(const i64* __restrict__ seg_eptr, i64 S, i64 tb, i64 bins, int kmax,
+                                            int* __restrict__ overflow) {
+  WalkBin b;
+  const i64 e0 = seg_eptr[0], etot = seg_eptr[S] - e0;
+  b.t0 = e0 + (tb * etot) / bins;
+  b.t1 = e0 + ((tb + 1) * etot) / bins;
+  b.s0 = 0; b.nk = 0;
+  if (b.t1 > b.t0) {
+    const i64 s0 = walk_upper(seg_eptr, S, b.t0) - 1, s1 = walk_upper(seg_eptr, S, b.t1 - 1) - 1;
+    b.s0 = (int)s0;
+    i64 nk = s1 - s0 + 1;
+    if (nk > kmax) {
+      if (overflow && (threadIdx.x & 63) == 0) atomicMax(overflow, (int)(nk < 0x7fffffff ? nk : 0x7fffffff));
+      nk = kmax;
+    }
+    b.nk = (int)nk;
+  }
+  return b;
+}
+// lane k of the wave: slots [c0, c1) of the bin's k-th row inside window w
+__device__ __forceinline__ void walk_granule(const WalkBin& b, const i64* __restrict__ seg_eptr,
+                                             const int* __restrict__ rw, i64 S, int w, int k, int& c0, int& c1) {
+  c0 = c1 = 0;
+  if (k >= b.nk) return;
+  const i64 s = b.s0 + k;
+  const i64 rs = seg_eptr[s], re = seg_eptr[s + 1], n = re - rs;
+  if (n <= 0) return;
+  const i64 a = (b.t0 > rs ? b.t0 : rs) - rs, e = (b.t1 < re ? b.t1 : re) - rs;
+  const i64 lo = rw[(i64)w * S + s], nw = rw[(i64)(w + 1) * S + s] - lo;
+  c0 = (int)(lo + (a * nw) / n);
+  c1 = (int)(lo + (e * nw) / n);
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(v, off);
+    if (lane >= off) v += up;
+  }
+  return v;
+}
+
+// one wave per bin; bin_len[tb * GW + g] = slots of lane group g, rounded up to 4
+__global__ __launch_bounds__(256) void k_walk_count(const i64* __restrict__ seg_eptr, const int* __restrict__ rw,
+                                                    i64 S, int W, i64 bins, int GW, int kmax,
+                                                    int* __restrict__ bin_len, int* __restrict__ overflow) {
+  const i64 tb = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k = threadIdx.x & 63;
+  if (tb >= bins) return;
+  const WalkBin b = walk_bin(seg_eptr, S, tb, bins, kmax, overflow);
+  int tot[4] = {0, 0, 0, 0};
+  for (int w = 0; w < W; ++w) {
+    int c0, c1;
+    walk_granule(b, seg_eptr, rw, S, w, k, c0, c1);
+    const int nw = __shfl(wave_incl_scan(c1 - c0, k), 63);
+    for (int g = 0; g < GW; ++g) tot[g] += (int)(((i64)(g + 1) * nw) / GW - ((i64)g * nw) / GW);
+  }
+  if (k < GW) bin_len[tb * GW + k] = (tot[k] + 3) & ~3;
+}
+
+__global__ __launch_bounds__(256) void k_walk_fill(const i64* __restrict__ seg_eptr, const int* __restrict__ rw,
+                                                   const i64* __restrict__ seg_chunk, const i64* __restrict__ row,
+                                                   const int32_t* __restrict__ idx32, const int32_t* __restrict__ eid32,
+                                                   i64 S, int W, i64 bins, int GW, int kmax,
+                                                   const int* __restrict__ bin_pos, int* __restrict__ ids,
+                                                   int* __restrict__ widx, int* __restrict__ bin_rows,
+                                                   int* __restrict__ bin_total) {
+  const i64 tb = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k = threadIdx.x & 63;
+  if (tb >= bins) return;
+  const WalkBin b = walk_bin(seg_eptr, S, tb, bins, kmax, nullptr);
+  if (k < kmax) {
+    int rec = -1;
+    if (k < b.nk) {
+      const i64 s = b.s0 + k;
+      const i64 rs = seg_eptr[s], re = seg_eptr[s + 1];
+      const bool shared = b.t0 > rs || b.t1 < re;
+      rec = (int)row[seg_chunk[s]] | (shared ? (int)0x80000000 : 0);
+    }
+    bin_rows[tb * kmax + k] = rec;
+  }
+  int run[4] = {0, 0, 0, 0};   // slots already written to each group's run (wave-uniform)
+  int base[4];
+  for (int g = 0; g < 4; ++g) base[g] = g < GW ? bin_pos[tb * GW + g] : 0;
+  for (int w = 0; w < W; ++w) {
+    int c0, c1;
+    walk_granule(b, seg_eptr, rw, S, w, k, c0, c1);
+    const int n = c1 - c0;
+    const int P = wave_incl_scan(n, k);
+    const int nw = __shfl(P, 63);
+    int bnd[5];
+    for (int g = 0; g <= 4; ++g) bnd[g] = g <= GW ? (int)(((i64)g * nw) / GW) : nw;
+    for (int kk = 0; kk < b.nk; ++kk) {
+      const int lo = __shfl(c0, kk), cnt = __shfl(n, kk), start = __shfl(P, kk) - cnt;
+      for (int i = k; i < cnt; i += 64) {
+        const int p = start + i;
+        int g = 0;
+        for (int gg = 1; gg < GW; ++gg) g = p >= bnd[gg] ? gg : g;
+        const int dst = base[g] + run[g] + (p - bnd[g]);
+        ids[dst] = (int)(((unsigned)kk << kWalkKShift) | (unsigned)idx32[lo + i]);
+        widx[dst] = eid32 ? eid32[lo + i] : lo + i;
+      }
+    }
+    for (int g = 0; g < GW; ++g) run[g] += bnd[g + 1] - bnd[g];
+  }
+  if (k < GW) bin_total[tb * GW + k] = run[k];
+}
+
 // ---- block-dense cover -----------------------------------------------------------------------------
 // same[s] = 1 when segment s has the same neighbour list (length and ids, in order) as segment
 // s - 1; also fills the 32-bit segment tables the block kernels read.
@@ -708,7 +837,116 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
   return GRAPHOP_OK;
 }
 
+// The walk layout of `p` for W windows of win_cols ids and a resident grid of `groups` lane groups
+// (built once per geometry, kept with the plan).  *out = nullptr when the graph does not fit the
+// layout (a bin would hold more than kWalkK rows at every round count tried, sizes beyond 31 bits).
+int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int xcd_slots, hipStream_t st,
+                  const Walk** out) {
+  auto* vec = (std::vector<Walk>*)p->walks;
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  *out = nullptr;
+  for (auto& w : *vec)
+    if (w.W == W && w.win_cols == win_cols && w.groups == groups && w.GW == GW && w.xcd_slots == xcd_slots) {
+      if (w.rounds > 0) *out = &w;    // rounds == 0: remembered as "does not fit"
+      return GRAPHOP_OK;
+    }
+  if (vec->size() >= 8) return GRAPHOP_OK;
+  {
+    const int rc_cap = check_not_capturing(st, "building the walk layout of a plan");
+    if (rc_cap != GRAPHOP_OK) return rc_cap;
+  }
+  const i64 S = p->info.n_segments, E = p->info.n_edges;
+  GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E > 0 && E < 0x7fffffffLL && S > 0 &&
+               W >= 1 && groups >= 1 && GW >= 1 && GW <= 4 && groups % GW == 0, "plan_get_walk: plan is not walkable");
+  Walk wk;
+  wk.W = W; wk.win_cols = win_cols; wk.groups = groups; wk.GW = GW; wk.xcd_slots = xcd_slots; wk.rounds = 0;
+  const int kmax = kWalkK * GW;     // rows per wave bin
+  const i64 waves = groups / GW;
+  auto remember_unfit = [&]() { vec->push_back(wk); return GRAPHOP_OK; };
+  if (p->info.max_index >= (1LL << kWalkKShift) || S * (W + 1) >= (i64)1 << 40) return remember_unfit();
+  const i64* indptr = (const i64*)p->indptr;
+  DevBuf seg_eptr, rw, len, ovf, tmp;
+  GO_HIP(go_malloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1), st));
+  hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
+                     (const i64*)p->seg_chunk, indptr, S, (i64*)seg_eptr.p);
+  GO_LAUNCH_CHECK();
+  GO_HIP(go_malloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1)), st));
+  hipLaunchKernelGGL(k_sweep_row_windows, dim3(grid_for(S * (W + 1), kBlock, 16384)), dim3(kBlock), 0, st,
+                     (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, win_cols, (int*)rw.p);
+  GO_LAUNCH_CHECK();
+  GO_HIP(go_malloc(&ovf.p, sizeof(int), st));
+  // fewest rounds whose bins all hold <= kmax rows: start where the mean bin holds ~80 % of that
+  i64 rounds = ceil_div(S * 10, waves * kmax * 8);
+  if (rounds < 1) rounds = 1;
+  i64 bins = 0;
+  bool fit = false;
+  for (int attempt = 0; attempt < 8 && !fit; ++attempt, ++rounds) {
+    bins = waves * rounds;
+    if (bins * GW >= (1 << 24)) break;
+    go_free(len.p); len.p = nullptr;
+    GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(bins * GW + 1), st));
+    GO_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), st));
+    GO_HIP(hipMemsetAsync(len.p, 0, sizeof(int) * (size_t)(bins * GW + 1), st));
+    hipLaunchKernelGGL(k_walk_count, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
+                       (const int*)rw.p, S, W, bins, GW, kmax, (int*)len.p, (int*)ovf.p);
+    GO_LAUNCH_CHECK();
+    int h_ovf = 0;
+    GO_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipStreamSynchronize(st));
+    fit = h_ovf == 0;
+    if (fit) break;
+  }
+  if (!fit) return remember_unfit();
+  size_t tmp_bytes = 0;
+  const i64 gbins = bins * GW;   // one run per lane group and round
+  GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)len.p, (int*)len.p, (int)(gbins + 1), st));
+  GO_HIP(go_malloc(&tmp.p, tmp_bytes ? tmp_bytes : 16, st));
+  GO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (int*)len.p, (int*)len.p, (int)(gbins + 1), st));
+  int total = 0;
+  GO_HIP(hipMemcpyAsync(&total, (int*)len.p + gbins, sizeof(int), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+  if (total < 0 || (i64)total > E + 4 * gbins) return remember_unfit();   // (scan wrapped: cannot happen below 2^31 slots)
+  wk.rounds = (int)rounds;
+  wk.n_slots = (i64)total + 1024;   // slack: a bin's last id segment is fetched whole
+  wk.max_steps = 8 * W < 1024 ? 8 * W : 1024;   // pacing steps per round (kernels_walk.h: WalkView::steps)
+  const i64 steps = rounds * wk.max_steps;
+  wk.sync_ints = 64LL * (8 + 16 * steps);
+  if (go_malloc((void**)&wk.ids, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
+      go_malloc((void**)&wk.widx, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
+      go_malloc((void**)&wk.bin_pos, sizeof(int) * (size_t)(gbins + 1), st) != hipSuccess ||
+      go_malloc((void**)&wk.bin_rows, sizeof(int) * (size_t)(bins * kmax), st) != hipSuccess ||
+      go_malloc((void**)&wk.bin_cum, sizeof(int) * (size_t)gbins, st) != hipSuccess ||
+      go_malloc((void**)&wk.sync, sizeof(int) * (size_t)wk.sync_ints, st) != hipSuccess) {
+    go_free(wk.ids); go_free(wk.widx); go_free(wk.bin_pos); go_free(wk.bin_rows); go_free(wk.bin_cum); go_free(wk.sync);
+    set_error("plan_get_walk: out of device memory for %lld slots", (long long)wk.n_slots);
+    return GRAPHOP_ERR_HIP;
+  }
+  auto fail = [&](int rc) {
+    go_free(wk.ids); go_free(wk.widx); go_free(wk.bin_pos); go_free(wk.bin_rows); go_free(wk.bin_cum); go_free(wk.sync);
+    return rc;
+  };
+  if (hipMemcpyAsync(wk.bin_pos, len.p, sizeof(int) * (size_t)(gbins + 1), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemsetAsync(wk.ids, 0, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
+      hipMemsetAsync(wk.widx, 0, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess)
+    return fail(GRAPHOP_ERR_HIP);
+  hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
+                     (const int*)rw.p, (const i64*)p->seg_chunk, (const i64*)p->row, (const int32_t*)p->idx32,
+                     (const int32_t*)(p->info.eid_identity ? nullptr : p->eid32), S, W, bins, GW, kmax,
+                     (const int*)wk.bin_pos, wk.ids, wk.widx, wk.bin_rows, wk.bin_cum);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
+  vec->push_back(wk);
+  *out = &vec->back();
+  return GRAPHOP_OK;
+}
+
 void plan_free_sweeps(graphop_plan* p) {
+  if (auto* wv = (std::vector<Walk>*)p->walks) {
+    for (auto& w : *wv) {
+      go_free(w.ids); go_free(w.widx); go_free(w.bin_pos); go_free(w.bin_rows); go_free(w.bin_cum); go_free(w.sync);
+    }
+    delete wv;
+    p->walks = nullptr;
+  }
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
     for (auto& s : *vec) {
@@ -725,6 +963,8 @@ void plan_free_sweeps(graphop_plan* p) {
 void plan_init_sweeps(graphop_plan* p) {
   p->sweeps = new std::vector<Sweep>();
   ((std::vector<Sweep>*)p->sweeps)->reserve(16);   // pointers handed out must stay valid
+  p->walks = new std::vector<Walk>();
+  ((std::vector<Walk>*)p->walks)->reserve(8);
   p->sweep_mu = new std::mutex();
 }
 

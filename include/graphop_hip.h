@@ -49,7 +49,7 @@ extern "C" {
 #define GRAPHOP_API
 #endif
 
-#define GRAPHOP_ABI_VERSION 4
+#define GRAPHOP_ABI_VERSION 5
 
 #define GRAPHOP_F32 0
 #define GRAPHOP_F64 1
@@ -91,9 +91,14 @@ GRAPHOP_API const char* graphop_last_error(void);
  * transpose_scalars, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
  * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile), attn_fused (0/1),
  * attn_window_scale, attn_k, attn_bpc (fused attention kernels), touch_sddmm (per-task id-line
- * touches of the SDDMM strips).  Not
+ * touches of the SDDMM strips), walk (bit 0 SDDMM-type, bit 1 row-major SpMM-type, bit 2 column-major
+ * SpMM-type passes on the walk drivers: lane groups own rows for a whole round and walk all column
+ * windows, nothing is flushed per window), walk_window_kb, walk_drift, walk_min_bin.  Not
  * thread-safe against concurrent op calls; results never depend on them. */
 GRAPHOP_API int graphop_tune(const char* key, int value);
+/* Every knob back to its default (the value at library load: built-in, or GRAPHOP_<KEY> from the
+ * environment).  Tests that turn knobs restore them with this, never with literals. */
+GRAPHOP_API int graphop_tune_reset(void);
 
 /* ---- device memory of plans ------------------------------------------------------------------
  * Plans own device arrays (per orientation: 8 B per chunk, 4-8 B per edge of 32-bit mirrors, and

@@ -1,0 +1,89 @@
+"""Walk drivers (csrc/kernels_walk.h): lane groups own a bin of rows for a whole round, keep the rows
+(partial sums / A rows) in LDS and walk all column windows; the plan cuts the CSR into equal bins
+(csrc/plan.hip: plan_get_walk).  Forced on small graphs through the tuning knobs, checked against
+the oracle, against the window-owner drivers and against the chunk drivers."""
+import pytest
+import torch
+
+from custom_op_benchmark_amd import _lib, graphs
+import oracle
+from util import random_graph, rand_inputs, oracle_step
+from test_hip_parity import hip_step, close
+
+pytestmark = pytest.mark.gpu
+
+WALK_KERNELS = {"k_sddmm_walk_f32", "k_spmm_walk_f32"}
+
+
+@pytest.fixture
+def force_walk():
+    _lib.tune_reset()
+    _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 8); _lib.tune("walk_min_bin", 0)
+    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512)
+    _lib.clear_plan_cache()
+    yield
+    _lib.tune_reset()
+    _lib.clear_plan_cache()
+
+
+def kernels_of(step):
+    _lib.profile_enable(True)
+    step()
+    torch.cuda.synchronize()
+    k = {r.get("kernel") for r in _lib.profile_read().values()}
+    _lib.profile_enable(False)
+    return k
+
+
+@pytest.mark.parametrize("blocks", [8, 24, 0])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_walk_vs_oracle(dev, force_walk, d, blocks):
+    """Rows cut by bin boundaries (merged by atomics), empty rows, empty windows, a hub row spanning many
+    bins, several rounds (small grids), bins of a handful of slots (the full grid on a small graph)."""
+    _lib.tune("walk_blocks", blocks)
+    n = 400 if d >= 256 else 1500
+    g = random_graph(n, n + 41, 10 * n, seed=77 + d + blocks, chunk_size=32, zero_rows=0.15, hub=900)
+    inp = rand_inputs(g, 1, d, seed=8, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+    got = hip_step(gd, *args)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
+    assert WALK_KERNELS <= kernels_of(lambda: hip_step(gd, *args))
+
+
+@pytest.mark.parametrize("drift", [0, 1, 2])
+def test_walk_matches_other_drivers_medium(dev, force_walk, drift):
+    """Same inputs through the walk, window-owner and chunk drivers: equal within fp32 re-association;
+    pacing on and off (results never depend on it)."""
+    _lib.tune("walk_drift", drift); _lib.tune("walk_window_kb", 256); _lib.tune("window_kb", 256)
+    g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
+    wk = hip_step(g, Q, K, V, dO)
+    assert WALK_KERNELS <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
+    _lib.tune("walk", 0)
+    sw = hip_step(g, Q, K, V, dO)
+    assert not (WALK_KERNELS & kernels_of(lambda: hip_step(g, Q, K, V, dO)))
+    _lib.tune("sweep", 0)
+    ch = hip_step(g, Q, K, V, dO)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        torch.testing.assert_close(wk[k], sw[k], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(wk[k], ch[k], rtol=2e-4, atol=2e-5)
+
+
+def test_walk_rows_longer_than_many_bins(dev, force_walk):
+    """One row holds a third of all slots: it is cut into pieces over dozens of bins (each piece takes its
+    share of every window) and merged by atomics; the other rows are short."""
+    n = 3000
+    gen = torch.Generator().manual_seed(5)
+    src = torch.cat([torch.randint(0, n, (40000,), generator=gen), torch.full((20000,), 17)])
+    dst = torch.randint(0, n, (60000,), generator=gen)
+    g = graphs.graph_from_coo(src, dst, n, n, chunk_size=32)
+    _lib.tune("walk_blocks", 16); _lib.tune("walk_window_kb", 64)
+    inp = rand_inputs(g, 1, 64, seed=3, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
