@@ -367,8 +367,10 @@ struct WalkDebug {
 
 // Decide whether the walk drivers apply to a pass over `plan` that gathers rows of 16*L*NV bytes from a
 // table of n_table_rows rows, and fetch / build the layout.  1 = use it, 0 = no, < 0 = error (negated).
+// `SH` = lane groups per bin of the layout (kernels_walk.h): 1 for the SpMM-type kernel, the lane groups of a
+// wave for the SDDMM-type kernel.
 template <int L, int NV>
-int choose_walk(const graphop_plan* plan, i64 n_table_rows, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
   if constexpr (NV != 1 || L < 16) {
     return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
   } else {
@@ -394,7 +396,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, hipStream_t st, Walk
     if (pi.n_edges < groups * (i64)t.walk_min_bin) return 0;
     static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc, "two walk workgroups per CU");
     const Walk* wk = nullptr;
-    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, kWave / L,
+    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, SH,
                                  slots, st, &wk);
     if (rc != GRAPHOP_OK) return -rc;
     if (!wk) return 0;
@@ -411,7 +413,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, hipStream_t st, Walk
       if (steps > wk->max_steps) steps = wk->max_steps;
       if (steps < 1) steps = 1;
       out->view.steps = (int)steps;
-      out->view.step_len = (int)(ceil_div(ceil_div(longest, steps), 2 * SB) * 2 * SB);   // (the kernels check every second batch)
+      out->view.step_len = (int)(ceil_div(ceil_div(longest, steps), SB) * SB);
     }
     out->view.drift = t.walk_drift;
     out->view.sync = t.walk_drift > 0 ? wk->sync : nullptr;
@@ -434,7 +436,7 @@ int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   } else {
     if (!(tuning().walk & 1) || h != 1 || !plan) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, st, &wl);
     if (use != 1) return use;
     static const bool attr = hipFuncSetAttribute((const void*)k_sddmm_walk_f32<L, NV>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
@@ -457,7 +459,7 @@ int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, c
     if (h != 1 || !plan) return 0;
     if (!(tuning().walk & (plan->info.eid_identity ? 2 : 4))) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, st, &wl);
     if (use != 1) return use;
     static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;

@@ -19,9 +19,11 @@
 // Where a bin stands in the table after a given share of its slots varies from bin to bin like
 // 1 / sqrt(slots per bin) (which windows a row's neighbours fall into is random): bins per wave
 // rather than per lane group halve that spread, which is what the L2 has to hold.
-// The lane groups of a wave share the bin's LDS rows: a row whose slots of one window are cut
-// between two groups is updated by both, so the read-modify-write of a partial sum is issued one
-// lane group at a time (LDS operations of one wave execute in order).
+// SH = lane groups that share one bin (template parameter of the kernels, `GW` of the layout):
+// SH = 1 is a bin per lane group (its rows are its own: partial sums are folded into LDS with a
+// plain, deferred read-modify-write); SH = lane groups of a wave is a bin per wave (measured on the
+// SDDMM-type passes, which only read the rows: 1.76 -> 1.66 ms on the Reddit shape; the SpMM-type
+// passes would have to order the updates of rows cut between two groups: 1.78 -> 2.03 ms).
 #pragma once
 #include "kernels_fast.h"
 
@@ -56,7 +58,7 @@ constexpr int kWalkBpc = 2;   // resident workgroups per CU the walk kernels are
 struct WalkPacer {
   int* ctr;
   int* reg;
-  int* lds;        // [0..7] waves of this workgroup done with step (s & 7); [8] highest released step + 1
+  int* lds;        // [0..3] steps finished by each wave; [4] steps forwarded to the XCD counters; [8] highest released step + 1
   int drift;
   int done_next;   // first step this wave has not signalled yet (wave-uniform)
   bool active;
@@ -76,23 +78,28 @@ struct WalkPacer {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
-  // every lane group of this wave has left all steps < upto (wave-uniform call, all lanes)
+  // every lane group of this wave has left all steps < upto (wave-uniform call, all lanes).  Each wave
+  // keeps its own progress word in LDS; whoever raises the workgroup's minimum forwards the newly
+  // finished steps to the XCD counters (an LDS atomic max hands every step to exactly one wave).
   __device__ __forceinline__ void signal_upto(int upto) {
     if (upto <= done_next) return;
+    done_next = upto;
     if (active && (threadIdx.x & (kWave - 1)) == 0) {
-      for (int st = done_next; st < upto; ++st) {
-        int* slot = lds + (st & 7);
-        const int old = __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (old == kWaves - 1) {            // last wave of this workgroup for step st
-          __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          int* c = ctr + (i64)st * 2 * kSyncStride;
-          const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (prev + 1 >= n) __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      __hip_atomic_store(lds + (threadIdx.x >> 6), upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int m = upto;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const int o = __hip_atomic_load(lds + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        m = o < m ? o : m;
+      }
+      const int from = __hip_atomic_fetch_max(lds + 4, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int st = from; st < m; ++st) {
+        int* c = ctr + (i64)st * 2 * kSyncStride;
+        const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 >= n) __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    done_next = upto;
   }
   // about to gather from `step`; own_min = the step the slowest lane group of this wave is in
   __device__ __forceinline__ void wait_enter(int step, int own_min) {
@@ -124,13 +131,13 @@ struct WalkPacer {
   }
 };
 
-template <int L>
-__device__ __forceinline__ i64 walk_bin_index(const WalkView& s, int r) {   // this wave's bin in round r
-  constexpr int WPB = kFastBlock / kWave, GW = kWave / L;
+template <int L, int SH>
+__device__ __forceinline__ i64 walk_bin_index(const WalkView& s, int r) {   // bin of this lane group's sharing set in round r
+  constexpr int SPB = kFastBlock / (L * SH);                // sharing sets per workgroup
   const int slots = s.xcd_slots;
   const i64 x = blockIdx.x % slots, i = blockIdx.x / slots;
-  const i64 per_slot = (s.groups / GW) / slots;            // waves per XCD slot
-  return ((i64)r * slots + x) * per_slot + i * WPB + (threadIdx.x >> 6);
+  const i64 per_slot = (s.groups / SH) / slots;             // sharing sets per XCD slot
+  return ((i64)r * slots + x) * per_slot + i * SPB + threadIdx.x / (L * SH);
 }
 
 template <int L>
@@ -145,119 +152,79 @@ __device__ __forceinline__ int wave_max_int(int v) {   // v group-uniform
   return m;
 }
 
-// LDS of one workgroup: [waves][kWalkK * GW] rows of 16*L*NV bytes, then the id rings.
+// LDS of one workgroup: [lane groups][kWalkK] rows of 16*L*NV bytes, then the id rings.
 template <int L, int NV>
 __host__ __device__ constexpr size_t walk_lds_bytes() {
   return (size_t)(kFastBlock / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)StageCfg<L, 2>::kLdsIntsPerGroup * 4);
 }
 
-// Both kernels keep TWO batches of rows in flight per lane group (the 256-VGPR budget of two waves per
-// SIMD pays for the second buffer): the row requests of batch b + 1 are issued before batch b is
-// consumed, so a wave always has 16 KB of gathers outstanding while it reduces / accumulates.
-
 // out[row] = sum over the row's slots of w[edge] * X[neighbour]   (graphop_kernel.cu:100-112, :118-130, :151-163)
+// Bins per lane group (SH = 1): the LDS rows are the group's own.
 template <int L, int NV>
 __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
     WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
   extern __shared__ float4 lds[];
-  constexpr int GPB = kFastBlock / L, GW = kWave / L, KW = kWalkK * GW;
+  constexpr int GPB = kFastBlock / L;
   constexpr i64 F4 = (i64)L * NV;
   constexpr int SB = StripCfg<L, NV>::SB;
-  static_assert(L >= 16 && KW <= kWave && KW <= (1 << (32 - kWalkKShift)), "lane k of a wave holds the bin's k-th row");
+  static_assert(L >= 16 && kWalkK <= L, "lane k of a group holds the bin's k-th row");
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
-  const int gq = g_in_blk % GW;                      // lane group inside the wave
-  const int lw = threadIdx.x & (kWave - 1);
-  float4* accs = lds + (i64)(threadIdx.x >> 6) * KW * F4;   // [KW][NV][L], shared by the wave's lane groups
+  float4* accs = lds + (i64)g_in_blk * kWalkK * F4;   // [kWalkK][NV][L]
   int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4) + g_in_blk * StageCfg<L, 2>::kLdsIntsPerGroup;
   __shared__ int pace_words[16];
   const long long t_start = __builtin_amdgcn_s_memtime();
   WalkPacer pacer(s, pace_words);
   for (int r = 0; r < s.rounds; ++r) {
-    const i64 tb = walk_bin_index<L>(s, r);
-    const i64 gb = tb * GW + gq;
-    const int pos0 = s.bin_pos[gb];
-    const int total = s.bin_cum[gb];
-    const int my_row = lw < KW ? s.bin_rows[tb * KW + lw] : -1;
+    const i64 tb = walk_bin_index<L, 1>(s, r);
+    const int pos0 = s.bin_pos[tb];
+    const int total = s.bin_cum[tb];
+    const int my_row = l < kWalkK ? s.bin_rows[tb * kWalkK + l] : -1;
     int next_step_at = 0;
-    for (int k = gq; k < KW; k += GW)
+#pragma unroll
+    for (int k = 0; k < kWalkK; ++k)
 #pragma unroll
       for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int wave_total = wave_max_int<L>(total);
     IdStage<L, 2> ids;
     if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
-    float4 acc[NV];
+    float4 acc[NV], pend_acc[NV], pend_rd[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k_cur = -1;
-    auto rmw = [&]() {
+    for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k_cur = -1, pend_k = -1;
+    // Row change: the partial sum of the row just left is folded into its LDS row by a DEFERRED
+    // read-modify-write -- the LDS row is requested now, added and written back at the NEXT row
+    // change -- so no LDS round trip sits between two slots' multiply-adds.  The rows are this lane
+    // group's own and a row's slots of one window are contiguous, so nobody touches the row in between.
+    auto finish_pending = [&]() {
+      if (pend_k >= 0) {
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float4 o = accs[(k_cur * NV + v) * L + l];
-        o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
-        accs[(k_cur * NV + v) * L + l] = o;
+        for (int v = 0; v < NV; ++v) {
+          float4 o = pend_rd[v];
+          o.x += pend_acc[v].x; o.y += pend_acc[v].y; o.z += pend_acc[v].z; o.w += pend_acc[v].w;
+          accs[(pend_k * NV + v) * L + l] = o;
+        }
       }
     };
-    // Partial sum of the row k_cur -> its LDS row.  The lane groups of a wave share the rows, and a row
-    // whose slots of one window are cut between two groups is held by both: when two of the groups
-    // that spill at this point hold the SAME row, the updates are issued one group at a time (LDS
-    // operations of one wave execute in order); otherwise all of them at once.
-    auto spill = [&]() {
+    auto row_change = [&](int kt) {
+      finish_pending();
+      pend_k = k_cur;
       if (k_cur >= 0) {
-        bool clash = false;
-        if constexpr (GW > 1) {
-          const unsigned long long act = __ballot(1);
-          int kq[GW];
 #pragma unroll
-          for (int q = 0; q < GW; ++q) kq[q] = ((act >> (q * L)) & 1) ? __builtin_amdgcn_readlane(k_cur, q * L) : -1 - q;
-#pragma unroll
-          for (int q = 0; q < GW; ++q)
-#pragma unroll
-            for (int p = q + 1; p < GW; ++p) clash |= kq[q] == kq[p];
+        for (int v = 0; v < NV; ++v) {
+          pend_acc[v] = acc[v];
+          pend_rd[v] = accs[(k_cur * NV + v) * L + l];
+          acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (!clash) {
-          rmw();
-        } else {
-#pragma unroll
-          for (int q = 0; q < GW; ++q) {
-            // (q is made opaque: to one thread the GW guarded copies are mutually exclusive and would
-            // be merged back into a single unguarded update)
-            int qq = q;
-            asm volatile("" : "+s"(qq) : : "memory");
-            if (gq == qq) rmw();
-            asm volatile("" ::: "memory");
-          }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      k_cur = kt;
     };
     struct Meta { int k; float w; };
-    auto issue = [&](int jb, float4 (&x)[SB][NV], Meta& m) {   // ids + weight of batch jb, then its row requests
-      ids.advance(jb);
-      const int jj = jb + l;
-      const bool live = l < SB && jj < total;
-      const int j = jj < total ? jj : total - 1;   // slots past the end re-read the last neighbour with weight 0
-      const int idw = ids.id(j);
-      m.k = (int)((unsigned)idw >> kWalkKShift);
-      const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
-      m.w = 0.f;
-      if (live) m.w = (s.experiment & 2) ? 1.f : wgt[ids.eid(j)];
-      static_for<SB>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const unsigned o = group_bcast<L, u>(my_off);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
-      });
-    };
     auto consume = [&](const float4 (&x)[SB][NV], const Meta& m) {
       static_for<SB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         const int kt = group_bcast<L, u>(m.k);
-        if (kt != k_cur) {   // group-uniform
-          spill();
-          k_cur = kt;
-        }
+        if (__builtin_expect(kt != k_cur, 0)) row_change(kt);   // group-uniform; about once per batch
         const float w1 = group_bcast<L, u>(m.w);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -268,30 +235,51 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
         }
       });
     };
-    float4 xa[SB][NV], xb[SB][NV];
-    Meta ma, mb;
-    ma.k = mb.k = 0; ma.w = mb.w = 0.f;
-    if (total > 0) issue(0, xa, ma);
-    for (int jb = 0; jb < wave_total; jb += 2 * SB) {
-      // pacing by progress: the lane groups of a wave hold equal shares of every window, and all bins
-      // hold the same number of slots (+- W), so equal positions in their runs mean nearly equal columns
+    // one batch of rows in flight per lane group; ids and weight of the next batch are fetched behind them
+    float4 x[SB][NV];
+    Meta mc, mn;
+    mc.k = mn.k = 0; mc.w = mn.w = 0.f;
+    unsigned off_c = 0, off_n = 0;
+    auto stage = [&](int jb, Meta& m, unsigned& off) {
+      ids.advance(jb);
+      const int jj = jb + l;
+      const bool live = l < SB && jj < total;
+      const int j = jj < total ? jj : total - 1;   // slots past the end re-read the last neighbour with weight 0
+      const int idw = ids.id(j);
+      m.k = (int)((unsigned)idw >> kWalkKShift);
+      off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
+      m.w = 0.f;
+      if (live) m.w = (s.experiment & 2) ? 1.f : wgt[ids.eid(j)];
+    };
+    if (total > 0) stage(0, mc, off_c);
+    for (int jb = 0; jb < wave_total; jb += SB) {
+      // pacing by progress: all bins hold the same number of slots (+- W), so equal positions in their
+      // runs mean nearly equal columns
       if (jb >= next_step_at) {   // wave-uniform
         const int step = r * s.steps + jb / s.step_len;
         pacer.signal_upto(step);
         pacer.wait_enter(step, step);
         next_step_at = (jb / s.step_len + 1) * s.step_len;
       }
-      if (jb + SB < total) issue(jb + SB, xb, mb);
-      if (jb < total) consume(xa, ma);
-      if (jb + 2 * SB < total) issue(jb + 2 * SB, xa, ma);
-      if (jb + SB < total) consume(xb, mb);
+      if (jb < total) {
+        static_for<SB>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          const unsigned o = group_bcast<L, u>(off_c);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
+        });
+        if (jb + SB < total) stage(jb + SB, mn, off_n);
+        consume(x, mc);
+        mc = mn; off_c = off_n;
+      }
     }
-    spill();
+    row_change(-1);      // the last row becomes the pending one ...
+    finish_pending();    // ... and is folded in
     pacer.signal_upto((r + 1) * s.steps);
     // the bin's rows leave the chip once: plain stores for rows that are wholly inside the bin, float
     // atomics for the (at most two) rows it shares with its neighbours
-    for (int k = gq; k < KW; k += GW) {
-      const int rec = __shfl(my_row, k);
+    for (int k = 0; k < kWalkK; ++k) {
+      const int rec = __shfl(my_row, k, L);
       if (rec == -1) continue;   // group-uniform
       const i64 row = rec & 0x7fffffff;
       float4 a[NV];
@@ -309,6 +297,7 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
 }
 
 // y[edge] = <A[row], B[neighbour]>   (graphop_kernel.cu:40-55, :135-149); h == 1
+// Bins per wave (SH = lane groups of a wave): the A rows in LDS are only read.
 template <int L, int NV>
 __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
     WalkView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y) {
@@ -328,7 +317,7 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
   WalkPacer pacer(s, pace_words);
   const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
   for (int r = 0; r < s.rounds; ++r) {
-    const i64 tb = walk_bin_index<L>(s, r);
+    const i64 tb = walk_bin_index<L, GW>(s, r);
     const i64 gb = tb * GW + gq;
     const int pos0 = s.bin_pos[gb];
     const int total = s.bin_cum[gb];
@@ -346,54 +335,44 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
     }
     float prev_res = 0.f;
     int prev_e = -1;
-    struct Meta { int e; unsigned koff; };
-    auto issue = [&](int jb, float4 (&b)[SB][NV], Meta& m) {
-      const int nb = (total - jb) < SB ? (total - jb) : SB;
-      ids.advance(jb);
-      const int j = (jb + l) < total ? jb + l : total - 1;   // lanes past the end re-read the last slot
-      const int idw = ids.id(j);
-      m.e = (l < nb) ? ids.eid(j) : -1;
-      m.koff = ((unsigned)idw >> kWalkKShift) * (unsigned)(F4 * 16);
-      const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
-      static_for<SB>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const unsigned o = group_bcast<L, u>(my_off);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
-      });
-    };
-    auto consume = [&](const float4 (&b)[SB][NV], const Meta& m) {
-      if (prev_e >= 0 && !(s.experiment & 2)) y[prev_e] = prev_res;   // behind the next batch's row requests
-      float part[SB];
-      static_for<SB>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const unsigned ko = group_bcast<L, u>(m.koff);
-        float4 av[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
-        float p = dot4(av[0], b[u][0]);
-#pragma unroll
-        for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
-        part[u] = p;
-      });
-      prev_res = group_dots_to_owner<L, SB>(part, l);
-      prev_e = m.e;
-    };
-    float4 ba[SB][NV], bb[SB][NV];
-    Meta ma, mb;
-    ma.e = mb.e = -1; ma.koff = mb.koff = 0;
-    if (total > 0) issue(0, ba, ma);
-    for (int jb = 0; jb < wave_total; jb += 2 * SB) {
+    for (int jb = 0; jb < wave_total; jb += SB) {
       if (jb >= next_step_at) {   // wave-uniform
         const int step = r * s.steps + jb / s.step_len;
         pacer.signal_upto(step);
         pacer.wait_enter(step, step);
         next_step_at = (jb / s.step_len + 1) * s.step_len;
       }
-      if (jb + SB < total) issue(jb + SB, bb, mb);
-      if (jb < total) consume(ba, ma);
-      if (jb + 2 * SB < total) issue(jb + 2 * SB, ba, ma);
-      if (jb + SB < total) consume(bb, mb);
+      if (jb < total) {
+        const int nb = (total - jb) < SB ? (total - jb) : SB;
+        ids.advance(jb);
+        const int j = (jb + l) < total ? jb + l : total - 1;   // lanes past the end re-read the last slot
+        const int idw = ids.id(j);
+        const int my_e = (l < nb) ? ids.eid(j) : -1;
+        const unsigned my_koff = ((unsigned)idw >> kWalkKShift) * (unsigned)(F4 * 16);
+        const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
+        float4 b[SB][NV];
+        static_for<SB>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          const unsigned o = group_bcast<L, u>(my_off);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
+        });
+        if (prev_e >= 0 && !(s.experiment & 2)) y[prev_e] = prev_res;   // behind the row requests (vmcnt retires in order)
+        float part[SB];
+        static_for<SB>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          const unsigned ko = group_bcast<L, u>(my_koff);
+          float4 av[NV];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
+          float p = dot4(av[0], b[u][0]);
+#pragma unroll
+          for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
+          part[u] = p;
+        });
+        prev_res = group_dots_to_owner<L, SB>(part, l);
+        prev_e = my_e;
+      }
     }
     if (prev_e >= 0) y[prev_e] = prev_res;
     pacer.signal_upto((r + 1) * s.steps);
