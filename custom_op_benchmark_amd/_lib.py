@@ -84,7 +84,7 @@ _SIGNATURES = {
     "graphop_attention_backward": [ctypes.c_int] + [_P] * 17 + [_c64] * 7 + [_P, _c64, _P, _P, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["graphop_abi_version", "graphop_last_error",
-                                               "graphop_plan_destroy"])
+                                               "graphop_plan_destroy", "graphop_memory_bytes"])
 
 
 def lib():
@@ -101,6 +101,8 @@ def lib():
         l.graphop_last_error.restype = ctypes.c_char_p
         l.graphop_plan_destroy.restype = None
         l.graphop_plan_destroy.argtypes = [_vp]
+        l.graphop_memory_bytes.restype = ctypes.c_int64
+        l.graphop_memory_bytes.argtypes = []
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = ctypes.c_int
@@ -142,8 +144,9 @@ def _drop_allocator(l):
 
 
 def plan_memory_bytes():
-    """Device bytes currently held by plans and their window structures (torch-allocated)."""
-    return sum(t.numel() for t in _live_blocks.values())
+    """Device bytes currently held by plans, their window structures and id layouts (whichever binding
+    created them: the library keeps the count, include/graphop_hip.h: graphop_memory_bytes)."""
+    return int(lib().graphop_memory_bytes())
 
 
 def check(rc):
@@ -388,6 +391,14 @@ def release_plans(*rows):
         plans = {id(e[4]) for e in lst}
         for k in [k for k, ent in _plan_cache.items() if any(id(p) in plans for p in ent.values())]:
             del _plan_cache[k]
+        ext = _cpp_ext()
+        if ext is not None and row.is_cuda:
+            ext.release_plans(row)      # the compiled extension keeps its own entries (csrc/torch_ext.cpp)
+
+
+def _cpp_ext():
+    from . import _ext
+    return _ext._mod        # only if it has been loaded: nothing to release otherwise
 
 
 def tune(key, value):
@@ -419,10 +430,14 @@ def profile_read():
 
 
 def clear_plan_cache():
+    """Drop every cached plan of both bindings (this one and the compiled extension's)."""
     for ent in _plan_cache.values():
         for p in ent.values():
             p.tensors[0].__dict__.pop("_graphop_plans", None)
     _plan_cache.clear()
+    ext = _cpp_ext()
+    if ext is not None:
+        ext.clear_plan_cache()
 
 
 # ---- partition_csr on the device ------------------------------------------------------------------

@@ -33,7 +33,9 @@ const char* get_error() { return g_err; }
 static graphop_alloc_fn g_alloc = nullptr;
 static graphop_free_fn g_free = nullptr;
 static std::mutex g_alloc_mu;
-static std::set<void*> g_hooked;   // pointers that came from g_alloc (freed through g_free only)
+static std::map<void*, size_t> g_hooked;   // pointers that came from g_alloc (freed through g_free only) -> bytes
+static std::map<void*, size_t> g_plain;    // pointers from hipMalloc -> bytes
+static size_t g_bytes = 0;                 // device bytes currently held through go_malloc (plans, their layouts, temporaries)
 
 hipError_t go_malloc(void** p, size_t bytes, hipStream_t st) {
   *p = nullptr;
@@ -46,19 +48,34 @@ hipError_t go_malloc(void** p, size_t bytes, hipStream_t st) {
     void* q = a(bytes, dev, (void*)st);
     if (!q) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    g_hooked.insert(q);
+    g_hooked[q] = bytes;
+    g_bytes += bytes;
     *p = q;
     return hipSuccess;
   }
-  return hipMalloc(p, bytes);
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_plain[*p] = bytes;
+    g_bytes += bytes;
+  }
+  return e;
 }
 void go_free(void* p) {
   if (!p) return;
   graphop_free_fn f = nullptr;
-  bool hooked;
+  bool hooked = false;
   {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    hooked = g_hooked.erase(p) > 0;
+    auto it = g_hooked.find(p);
+    if (it != g_hooked.end()) {
+      hooked = true;
+      g_bytes -= it->second;
+      g_hooked.erase(it);
+    } else {
+      auto jt = g_plain.find(p);
+      if (jt != g_plain.end()) { g_bytes -= jt->second; g_plain.erase(jt); }
+    }
     f = g_free;
   }
   if (hooked) { if (f) f(p); return; }   // (allocator gone at shutdown: left to process exit)
@@ -233,6 +250,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   const Sweep* sw = nullptr;
   const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
   if (rc != GRAPHOP_OK) return -rc;
+  if (!sw) return 0;   // the plan already holds its share of window geometries: chunk drivers for this one
   out->window_owner = t.sweep_mode == 1 && !force_windows;
   if (out->window_owner) {
     // window-owner drivers: a resident grid of waves pulling (window, vrow tile) tasks from the
@@ -333,25 +351,27 @@ struct WalkDebug {
   unsigned blocks = 0;
   const char* tag = "";
   hipStream_t st = nullptr;
-  int rounds = 0, W = 0;
-  void arm(WalkLaunch* wl, const char* t, hipStream_t s) {
+  int rounds = 0, W = 0, waves_per_wg = 4;
+  void arm(WalkLaunch* wl, const char* t, hipStream_t s, int wpw = 4) {
+    waves_per_wg = wpw;
     if (!tuning().walk_debug) return;
     blocks = wl->blocks; tag = t; st = s; rounds = wl->view.rounds; W = wl->view.steps;
-    if (hipMalloc((void**)&buf, sizeof(long long) * 16 * blocks) != hipSuccess) { buf = nullptr; return; }
-    (void)hipMemsetAsync(buf, 0, sizeof(long long) * 16 * blocks, s);
+    if (hipMalloc((void**)&buf, sizeof(long long) * 34 * blocks) != hipSuccess) { buf = nullptr; return; }
+    (void)hipMemsetAsync(buf, 0, sizeof(long long) * 34 * blocks, s);
     wl->view.dbg = buf;
   }
   ~WalkDebug() {
     if (!buf) return;
-    std::vector<long long> h((size_t)16 * blocks);
+    std::vector<long long> h((size_t)34 * blocks);
     if (hipStreamSynchronize(st) == hipSuccess &&
         hipMemcpy(h.data(), buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-      double tot = 0, wait = 0, nw = 0; long long tmax = 0, tmin = 1LL << 62; int gave = 0;
+      double tot = 0, wait = 0, nw = 0, feed = 0, ftot = 0, fspace = 0; long long tmax = 0, tmin = 1LL << 62; int gave = 0;
+      for (size_t b = 0; b < blocks; ++b) { ftot += h[(size_t)32 * blocks + 2 * b]; fspace += h[(size_t)32 * blocks + 2 * b + 1]; }
       double xt[8] = {0}, xw[8] = {0}; int xn[8] = {0};
-      const size_t n = (size_t)4 * blocks;
+      const size_t n = (size_t)waves_per_wg * blocks;
       for (size_t i = 0; i < n; ++i) {
         const long long* d = &h[i * 4];
-        tot += d[0]; wait += d[1]; nw += d[2];
+        tot += d[0]; wait += d[1]; nw += d[2] & 0xffff; feed += (double)(d[2] >> 16);
         tmax = d[0] > tmax ? d[0] : tmax; tmin = d[0] < tmin ? d[0] : tmin;
         gave += (d[3] & 16) ? 1 : 0;
         const int x = (int)(d[3] & 7); xt[x] += d[0]; xw[x] += d[1]; xn[x]++;
@@ -359,6 +379,8 @@ struct WalkDebug {
       fprintf(stderr, "[walk] %s rounds=%d steps=%d waves=%zu cycles mean %.0f min %lld max %lld | pacer wait %.1f %% of wave time, %.1f waits/wave, %d gave up | per XCD wait%%:",
               tag, rounds, W, n, tot / n, tmin, tmax, 100.0 * wait / (tot > 0 ? tot : 1), nw / n, gave);
       for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f(%d)", xn[x] ? 100.0 * xw[x] / (xt[x] > 0 ? xt[x] : 1) : 0.0, xn[x]);
+      fprintf(stderr, " | workers wait for the feeder %.1f %%; feeder: %.0f cycles, %.1f %% waiting for ring space", 100.0 * feed / (tot > 0 ? tot : 1),
+              ftot / (blocks ? blocks : 1), 100.0 * fspace / (ftot > 0 ? ftot : 1));
       fprintf(stderr, "\n");
     }
     (void)hipFree(buf);
@@ -370,7 +392,8 @@ struct WalkDebug {
 // `SH` = lane groups per bin of the layout (kernels_walk.h): 1 for the SpMM-type kernel, the lane groups of a
 // wave for the SDDMM-type kernel.
 template <int L, int NV>
-int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_threads, int wgs_per_cu, hipStream_t st,
+                WalkLaunch* out, bool dry_run = false) {
   if constexpr (NV != 1 || L < 16) {
     return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
   } else {
@@ -383,18 +406,19 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, hipStream_t 
     if (pi.max_index >= (1LL << kWalkKShift)) return 0;
     const i64 table_bytes = n_table_rows * 16LL * L * NV;
     if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
-    i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes, (i64)t.walk_window_kb * 1024));
+    const i64 win_kb = pi.eid_identity ? t.walk_window_kb : t.walk_window_kb_col;
+    i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes, (win_kb > 0 ? win_kb : 1) * 1024));
     if (W < 2) W = 2;
     if (W > t.max_windows || W > 512) return 0;
     const i64 mean_row = pi.n_edges / pi.n_segments;
     if (mean_row < (i64)t.sweep_min_granule * W / 2) return 0;
-    constexpr int GPB = kFastBlock / L;
-    i64 blocks = t.walk_blocks > 0 ? t.walk_blocks : (i64)t.n_cu * kWalkBpc;
+    const int GPB = worker_threads / L;
+    i64 blocks = t.walk_blocks > 0 ? ceil_div((i64)t.walk_blocks * kFastBlock, worker_threads) : (i64)t.n_cu * wgs_per_cu;
     int slots = 8;
     if (blocks >= 8) blocks -= blocks % 8; else slots = 1;
     const i64 groups = blocks * GPB;
     if (pi.n_edges < groups * (i64)t.walk_min_bin) return 0;
-    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc, "two walk workgroups per CU");
+    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc && spmm_walk_lds_bytes<L, NV>() + 1024 <= 160 * 1024, "LDS per CU");
     const Walk* wk = nullptr;
     const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, SH,
                                  slots, st, &wk);
@@ -415,6 +439,9 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, hipStream_t 
       out->view.steps = (int)steps;
       out->view.step_len = (int)(ceil_div(ceil_div(longest, steps), SB) * SB);
     }
+    out->view.win_cols = wk->win_cols;
+    out->view.table_bytes = t.walk_prefetch ? table_bytes : 0;
+    out->view.xcd_wgs = (int)(blocks / slots);
     out->view.drift = t.walk_drift;
     out->view.sync = t.walk_drift > 0 ? wk->sync : nullptr;
     out->view.dbg = nullptr;
@@ -436,7 +463,7 @@ int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   } else {
     if (!(tuning().walk & 1) || h != 1 || !plan) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kFastBlock, kWalkBpc, st, &wl);
     if (use != 1) return use;
     static const bool attr = hipFuncSetAttribute((const void*)k_sddmm_walk_f32<L, NV>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
@@ -459,15 +486,25 @@ int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, c
     if (h != 1 || !plan) return 0;
     if (!(tuning().walk & (plan->info.eid_identity ? 2 : 4))) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, kWalkWorkers, 1, st, &wl);
     if (use != 1) return use;
     static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
     (void)attr;
+    static_assert(spmm_walk_lds_bytes<L, NV>() + 1024 <= 160 * 1024, "one walk workgroup per CU");
     WalkDebug dbg;
-    dbg.arm(&wl, tag, st);
+    dbg.arm(&wl, tag, st, kWalkWorkers / kWave);
     ProfScope prof(tag, st, "k_spmm_walk_f32");
-    hipLaunchKernelGGL((k_spmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kFastBlock), wl.lds_bytes, st, wl.view,
+    constexpr size_t lds_bytes = spmm_walk_lds_bytes<L, NV>();
+    if (tuning().walk_debug) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spmm_walk_f32<L, NV>, kWalkThreads, lds_bytes);
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, (const void*)k_spmm_walk_f32<L, NV>);
+      fprintf(stderr, "[walk] occupancy API: %d workgroups of %d threads per CU (dynamic LDS %zu, static %zu, regs %d)\n", nb, kWalkThreads,
+              lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs);
+    }
+    hipLaunchKernelGGL((k_spmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view,
                        (const float*)w, (const float*)X, (float*)out);
     return 1;
   }
@@ -947,8 +984,9 @@ int graphop_tune(const char* key, int value) {
       {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
       {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
-      {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb},
-      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps}};
+      {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
+      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps},
+      {"walk_prefetch", &t.walk_prefetch}};
   for (auto& e : tab)
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
@@ -956,6 +994,11 @@ int graphop_tune(const char* key, int value) {
     }
   set_error("tune: unknown key '%s'", key);
   return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
+int64_t graphop_memory_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  return (int64_t)g_bytes;
 }
 
 int graphop_tune_reset(void) {

@@ -50,9 +50,12 @@ struct Tuning {
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
   int walk;               // walk drivers (kernels_walk.h): bit 0 SDDMM-type passes, bit 1 SpMM-type over identity-eid
                           // (row-major) slots, bit 2 SpMM-type over permuted (column-major) slots
-  int walk_window_kb;     // bytes of gathered table per window of the walk drivers (two windows live in a 4 MiB L2)
+  int walk_window_kb;     // bytes of gathered table per window of the walk drivers, passes over identity-eid (row-major) slots
+  int walk_window_kb_col; // ... passes over permuted (column-major) slots: their per-slot scalars are a gather whose lines
+                          // share the L2 with the window (Reddit shape: 2.72 ms at 4 MB, 2.25 at 2 MB; row-major 1.71 / 1.78)
   int walk_drift;         // pacing steps a wave may run ahead of the slowest wave of its XCD (0 = free-running)
   int walk_steps;         // pacing steps per column window
+  int walk_prefetch;      // the feeder wave of the SpMM-type walk kernel touches the next window's share of the table
   int walk_min_bin;       // fewest slots per (lane group, round) bin for the walk drivers to be chosen
   int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
   int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
@@ -84,10 +87,12 @@ struct Tuning {
     attn_max_d = env_int("GRAPHOP_ATTN_MAX_D", 64);
     staged_ids = env_int("GRAPHOP_STAGED_IDS", 7);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
-    walk = env_int("GRAPHOP_WALK", 7);
-    walk_window_kb = env_int("GRAPHOP_WALK_WINDOW_KB", 2048);
+    walk = env_int("GRAPHOP_WALK", 6);   // SDDMM-type passes: the window-owner drivers measure 1.55-1.6 ms against 1.63-1.73
+    walk_window_kb = env_int("GRAPHOP_WALK_WINDOW_KB", 4096);
+    walk_window_kb_col = env_int("GRAPHOP_WALK_WINDOW_KB_COL", 2048);
     walk_drift = env_int("GRAPHOP_WALK_DRIFT", 2);
-    walk_steps = env_int("GRAPHOP_WALK_STEPS", 2);
+    walk_steps = env_int("GRAPHOP_WALK_STEPS", 1);
+    walk_prefetch = env_int("GRAPHOP_WALK_PREFETCH", 0);   // measured on the Reddit shape: 1.78 -> 2.05 ms per row-major pass with it
     walk_min_bin = env_int("GRAPHOP_WALK_MIN_BIN", 1024);
     walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);

@@ -41,6 +41,9 @@ struct WalkView {
   int step_len;          // slots per pacing step (multiple of the batch size; steps * step_len >= the longest bin)
   int drift;             // a wave may start step s only once every wave of its XCD has left step s - drift
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
+  i64 win_cols;          // ids per column window
+  i64 table_bytes;       // bytes of the gathered table (0: the feeder does not touch it ahead)
+  int xcd_wgs;           // workgroups per XCD slot (each touches its share of the next window)
   int experiment;        // measurement variants (WRONG RESULTS): bit 0 every gather inside one 2 MB region, bit 1 no weight loads / result stores
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
 };
@@ -58,15 +61,15 @@ constexpr int kWalkBpc = 2;   // resident workgroups per CU the walk kernels are
 struct WalkPacer {
   int* ctr;
   int* reg;
-  int* lds;        // [0..3] steps finished by each wave; [4] steps forwarded to the XCD counters; [8] highest released step + 1
+  int* lds;        // [0..7] steps finished by each worker wave; [8] steps forwarded to the XCD counters; [9] highest released step + 1
   int drift;
   int done_next;   // first step this wave has not signalled yet (wave-uniform)
   bool active;
-  long long t_wait = 0, n_wait = 0;   // diagnostics
-  static constexpr int kWaves = kFastBlock / kWave;
-  __device__ __forceinline__ WalkPacer(const WalkView& s, int* lds_words)
+  long long t_wait = 0, n_wait = 0, t_feed = 0;   // diagnostics
+  int n_waves;     // worker waves of the workgroup (<= 8)
+  __device__ __forceinline__ WalkPacer(const WalkView& s, int* lds_words, int worker_waves = kFastBlock / kWave)
       : ctr(nullptr), reg(nullptr), lds(lds_words), drift(s.drift), done_next(0),
-        active(s.sync != nullptr && s.drift > 0) {
+        active(s.sync != nullptr && s.drift > 0), n_waves(worker_waves) {
     if (!active) return;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -74,7 +77,7 @@ struct WalkPacer {
     const i64 steps = (i64)s.rounds * s.steps;
     reg = s.sync + (i64)xcc * kSyncStride;
     ctr = s.sync + (i64)kSyncStride * (kSyncXcds + 2 * (i64)xcc * steps);
-    if (threadIdx.x < 9) lds[threadIdx.x] = 0;
+    if (threadIdx.x < 12) lds[threadIdx.x] = 0;
     if (threadIdx.x == 0) __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
@@ -87,12 +90,11 @@ struct WalkPacer {
     if (active && (threadIdx.x & (kWave - 1)) == 0) {
       __hip_atomic_store(lds + (threadIdx.x >> 6), upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       int m = upto;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
+      for (int w = 0; w < n_waves; ++w) {
         const int o = __hip_atomic_load(lds + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         m = o < m ? o : m;
       }
-      const int from = __hip_atomic_fetch_max(lds + 4, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int from = __hip_atomic_fetch_max(lds + 8, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       for (int st = from; st < m; ++st) {
         int* c = ctr + (i64)st * 2 * kSyncStride;
         const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -108,14 +110,14 @@ struct WalkPacer {
     int gave_up = 0;
     const long long t0 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & (kWave - 1)) == 0 &&
-        __hip_atomic_load(lds + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= need) {
+        __hip_atomic_load(lds + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= need) {
       const int* rel = ctr + ((i64)need * 2 + 1) * kSyncStride;
       int it = 0;
       while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(8);
         if (++it > 3000) { gave_up = 1; break; }   // ~2 ms without progress: give up pacing for good
       }
-      if (!gave_up) __hip_atomic_fetch_max(lds + 8, need + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!gave_up) __hip_atomic_fetch_max(lds + 9, need + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (__shfl(gave_up, 0)) active = false;
     t_wait += __builtin_amdgcn_s_memtime() - t0;
@@ -125,8 +127,8 @@ struct WalkPacer {
     if (dbg && (threadIdx.x & (kWave - 1)) == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      long long* d = dbg + ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 4;
-      d[0] = __builtin_amdgcn_s_memtime() - t_start; d[1] = t_wait; d[2] = n_wait; d[3] = (active ? 0 : 16) + (xcc & 7);
+      long long* d = dbg + ((long long)blockIdx.x * n_waves + (threadIdx.x >> 6)) * 4;
+      d[0] = __builtin_amdgcn_s_memtime() - t_start; d[1] = t_wait; d[2] = n_wait + (t_feed << 16); d[3] = (active ? 0 : 16) + (xcc & 7);
     }
   }
 };
@@ -138,6 +140,14 @@ __device__ __forceinline__ i64 walk_bin_index(const WalkView& s, int r) {   // b
   const i64 x = blockIdx.x % slots, i = blockIdx.x / slots;
   const i64 per_slot = (s.groups / SH) / slots;             // sharing sets per XCD slot
   return ((i64)r * slots + x) * per_slot + i * SPB + threadIdx.x / (L * SH);
+}
+
+template <int GPB>
+__device__ __forceinline__ i64 walk_bin_index_of(const WalkView& s, int r, int g_in_blk) {   // bins per lane group
+  const int slots = s.xcd_slots;
+  const i64 x = blockIdx.x % slots, i = blockIdx.x / slots;
+  const i64 per_slot = s.groups / slots;
+  return ((i64)r * slots + x) * per_slot + i * GPB + g_in_blk;
 }
 
 template <int L>
@@ -158,26 +168,190 @@ __host__ __device__ constexpr size_t walk_lds_bytes() {
   return (size_t)(kFastBlock / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)StageCfg<L, 2>::kLdsIntsPerGroup * 4);
 }
 
+// ---- SpMM-type walk kernel: eight worker waves + four FEEDER waves per workgroup --------------------------
+// Vector-memory operations of a wave return in issue order, so every small load between two batches
+// of row requests -- the ids of the next batches, above all the per-slot weight w[edge] (a 4-byte
+// gather over the whole edge array in the column-major passes) -- holds back the rows queued behind
+// it for a trip to the Infinity Cache or HBM.  Here the worker waves issue row requests and nothing
+// else: the feeder waves of the workgroup read the lane groups' (id, edge id) runs a chunk of
+// kFeedChunk slots at a time, gathers the weights, and leaves ids and weights in a small LDS ring per
+// lane group (kFeedRing chunks); it also touches the next column window's share of the table when
+// its lane group 0 enters a window, so the first gather of a row in a round finds it in L2.
+// Hand-over per (lane group, chunk) through two LDS words: `ready` = chunks written by the
+// feeder, `done` = chunks the lane group has finished reading (LDS operations of a wave execute in
+// order; the words are accessed with relaxed workgroup-scope atomics between compiler barriers).
+constexpr int kFeedChunk = kWave; // slots per chunk (four batches): one per feeder lane
+constexpr int kFeedRing = 2;      // chunks per ring
+// One workgroup per CU: 8 worker waves + 4 feeder waves = three waves on every SIMD.  (Two workgroups
+// of 5 or 6 waves do not pack: with <= 168 VGPRs a SIMD takes three waves, and a workgroup whose wave
+// count is not a multiple of four leaves the second one waiting for a SIMD slot.)
+constexpr int kWalkWorkers = 512;  // worker threads
+constexpr int kFeeders = 4;        // feeder waves, each serving GPB / kFeeders lane groups
+constexpr int kWalkThreads = kWalkWorkers + kFeeders * kWave;
+
+template <int L, int NV>
+__host__ __device__ constexpr size_t spmm_walk_lds_bytes() {
+  return (size_t)(kWalkWorkers / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)kFeedChunk * kFeedRing * 8);
+}
+
+__device__ __forceinline__ int lds_ld(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_st(int* p, int v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
 // out[row] = sum over the row's slots of w[edge] * X[neighbour]   (graphop_kernel.cu:100-112, :118-130, :151-163)
 // Bins per lane group (SH = 1): the LDS rows are the group's own.
 template <int L, int NV>
-__global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
+__global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second bound: waves per SIMD)
     WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
   extern __shared__ float4 lds[];
-  constexpr int GPB = kFastBlock / L;
+  constexpr int GPB = kWalkWorkers / L;
   constexpr i64 F4 = (i64)L * NV;
   constexpr int SB = StripCfg<L, NV>::SB;
-  static_assert(L >= 16 && kWalkK <= L, "lane k of a group holds the bin's k-th row");
+  constexpr int RING = kFeedChunk * kFeedRing;
+  static_assert(L >= 16 && kWalkK <= L && SB == 16 && kFeedChunk % SB == 0, "lane k of a group holds the bin's k-th row");
+  __shared__ int pace_words[16];
+  __shared__ int feed_ready[GPB], feed_done[GPB];
+  int* ring_base = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4);   // [GPB][2][RING]: ids, weights
+  if (threadIdx.x < GPB) { feed_ready[threadIdx.x] = 0; feed_done[threadIdx.x] = 0; }
+  const long long t_start = __builtin_amdgcn_s_memtime();
+  WalkPacer pacer(s, pace_words, kWalkWorkers / kWave);    // (its barrier also publishes the zeroed hand-over words)
+
+  if (threadIdx.x >= kWalkWorkers) {
+    // ---------------- feeder wave ----------------
+    // One wave instruction serves one lane group: a CHUNK of kFeedChunk = 64 slots, one per feeder lane.  Per
+    // lane group the feeder holds two chunks in registers -- chunk c with its weights requested, chunk
+    // c + 1 with its (id, edge id) pair requested -- and ADVANCES a group when the ring has room for
+    // chunk c: write c, request the weights of c + 1, request the pair of c + 2.  Every request thus
+    // has a whole chunk time (the group needs ~13 k cycles per chunk) to come back, and the groups
+    // advance independently of each other.
+    const int h = (threadIdx.x - kWalkWorkers) % kWave;
+    constexpr int NG = GPB / kFeeders > 0 ? GPB / kFeeders : 1;   // lane groups of this feeder
+    const int g0 = ((threadIdx.x - kWalkWorkers) / kWave) * NG;
+    if (g0 >= GPB) return;
+    int chunk_base[NG];                               // chunks of earlier rounds (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) chunk_base[g] = 0;
+    int last_win = -1;
+    int pf[4] = {0, 0, 0, 0};
+    long long t_space = 0;
+    for (int r = 0; r < s.rounds; ++r) {
+      int pos0[NG], total[NG], nchunk[NG], c[NG];
+      int idW[NG], idA[NG], wiA[NG], wi0[NG];
+      float wvW[NG];
+      auto load_pair = [&](int g, int ck, int& idw, int& wi) {
+        idw = 0; wi = -1;
+        if (ck * kFeedChunk < total[g]) {
+          const int j = ck * kFeedChunk + h;
+          const int jc = j < total[g] ? j : total[g] - 1;   // the tail of the last chunk repeats the last neighbour, weight 0
+          idw = s.ids[pos0[g] + jc];
+          if (j < total[g]) wi = s.widx[pos0[g] + jc];
+        }
+      };
+      int left = 0;
+      {
+        int p_l = 0, t_l = 0;                         // lane g < NG: run start / length of lane group g0 + g
+        if (h < NG) {
+          const i64 tb = walk_bin_index_of<GPB>(s, r, g0 + h);
+          p_l = s.bin_pos[tb];
+          t_l = s.bin_cum[tb];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          pos0[g] = __builtin_amdgcn_readlane(p_l, g);
+          total[g] = __builtin_amdgcn_readlane(t_l, g);
+          nchunk[g] = (total[g] + kFeedChunk - 1) / kFeedChunk;
+          c[g] = 0;
+          left += nchunk[g];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) load_pair(g, 0, idW[g], wi0[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) load_pair(g, 1, idA[g], wiA[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) wvW[g] = wi0[g] >= 0 ? wgt[wi0[g]] : 0.f;
+      while (left > 0) {
+        // one TURN: every lane group whose ring has room advances by a chunk.  All ring writes first (they
+        // use what the previous turn requested: one wait per turn), then all weight requests, then all
+        // (id, edge id) requests.
+        const int done_l = h < NG ? lds_ld(feed_done + g0 + h) : 0;
+        unsigned adv = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (c[g] >= nchunk[g]) continue;                                // wave-uniform
+          const int gc = chunk_base[g] + c[g];                            // running chunk number of this lane group
+          if (gc - __builtin_amdgcn_readlane(done_l, g) >= kFeedRing) continue;   // ring full: the group is still reading
+          adv |= 1u << g;
+          int* ring = ring_base + (g0 + g) * 2 * RING;
+          const int at = (gc % kFeedRing) * kFeedChunk + h;
+          ring[at] = idW[g];
+          ring[RING + at] = __float_as_int(wvW[g]);
+          lds_st(feed_ready + g0 + g, gc + 1);
+        }
+        if (adv == 0) {
+          const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
+          __builtin_amdgcn_s_sleep(4);
+          if (s.dbg) t_space += __builtin_amdgcn_s_memtime() - t0;
+          continue;
+        }
+        // the next window's share of the table -> this XCD's L2 (speed only): when lane group 0 enters a window
+        if ((adv & 1) && g0 == 0 && s.table_bytes > 0) {
+          const int win = (int)((i64)__builtin_amdgcn_readfirstlane(idW[0] & kWalkIdMask) / s.win_cols);
+          if (win != last_win) {
+            last_win = win;
+            asm volatile("; prefetched %0 %1 %2 %3" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+            const i64 wb = (i64)s.win_cols * (F4 * 16);                 // bytes per window
+            const i64 share = ((wb / s.xcd_wgs) + 63) & ~(i64)63;       // this workgroup's share
+            const i64 lo = (i64)(win + 1) * wb + (i64)(blockIdx.x / s.xcd_slots) * share;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pf[q] = 0;
+            for (i64 o = (i64)h * 64, q = 0; o < share && q < 16; o += kWave * 64, ++q) {
+              const i64 at2 = lo + o;
+              if (at2 + 4 <= s.table_bytes && at2 < (i64)(win + 2) * wb)
+                pf[q & 3] += *reinterpret_cast<const int*>(reinterpret_cast<const char*>(X) + at2);
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (!((adv >> g) & 1)) continue;
+          idW[g] = idA[g];
+          wvW[g] = wiA[g] >= 0 ? wgt[wiA[g]] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (!((adv >> g) & 1)) continue;
+          load_pair(g, c[g] + 2, idA[g], wiA[g]);
+          ++c[g];
+          --left;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) chunk_base[g] += nchunk[g];
+    }
+    asm volatile("; prefetched %0 %1 %2 %3" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+    if (s.dbg && h == 0 && g0 == 0) {
+      long long* d = s.dbg + (long long)gridDim.x * 32 + (long long)blockIdx.x * 2;
+      d[0] = __builtin_amdgcn_s_memtime() - t_start; d[1] = t_space;
+    }
+    return;
+  }
+
+  // ---------------- worker waves ----------------
   const int l = threadIdx.x % L;
   const int g_in_blk = threadIdx.x / L;
   float4* accs = lds + (i64)g_in_blk * kWalkK * F4;   // [kWalkK][NV][L]
-  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4) + g_in_blk * StageCfg<L, 2>::kLdsIntsPerGroup;
-  __shared__ int pace_words[16];
-  const long long t_start = __builtin_amdgcn_s_memtime();
-  WalkPacer pacer(s, pace_words);
+  const int* ring = ring_base + g_in_blk * 2 * RING;
+  int seg_base = 0;                                   // segments of earlier rounds
   for (int r = 0; r < s.rounds; ++r) {
-    const i64 tb = walk_bin_index<L, 1>(s, r);
-    const int pos0 = s.bin_pos[tb];
+    const i64 tb = walk_bin_index_of<GPB>(s, r, g_in_blk);
     const int total = s.bin_cum[tb];
     const int my_row = l < kWalkK ? s.bin_rows[tb * kWalkK + l] : -1;
     int next_step_at = 0;
@@ -186,8 +360,6 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
 #pragma unroll
       for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int wave_total = wave_max_int<L>(total);
-    IdStage<L, 2> ids;
-    if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
     float4 acc[NV], pend_acc[NV], pend_rd[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -235,21 +407,28 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
         }
       });
     };
-    // one batch of rows in flight per lane group; ids and weight of the next batch are fetched behind them
+    // one batch of rows in flight per lane group; id and weight of the next batch come from the feeder's ring
     float4 x[SB][NV];
     Meta mc, mn;
     mc.k = mn.k = 0; mc.w = mn.w = 0.f;
     unsigned off_c = 0, off_n = 0;
     auto stage = [&](int jb, Meta& m, unsigned& off) {
-      ids.advance(jb);
-      const int jj = jb + l;
-      const bool live = l < SB && jj < total;
-      const int j = jj < total ? jj : total - 1;   // slots past the end re-read the last neighbour with weight 0
-      const int idw = ids.id(j);
+      if ((jb % kFeedChunk) == 0) {                   // entering a chunk: earlier ones are read, this one must be there
+        const int gs = seg_base + jb / kFeedChunk;
+        lds_st(feed_done + g_in_blk, gs);
+        int it = 0;
+        const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
+        while (lds_ld(feed_ready + g_in_blk) <= gs) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++it > (1 << 22)) break;                // (never observed; bounds the spin)
+        }
+        if (s.dbg) pacer.t_feed += __builtin_amdgcn_s_memtime() - t0;
+      }
+      const int at = (seg_base * kFeedChunk + jb + l) % RING;
+      const int idw = ring[at];
       m.k = (int)((unsigned)idw >> kWalkKShift);
       off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
-      m.w = 0.f;
-      if (live) m.w = (s.experiment & 2) ? 1.f : wgt[ids.eid(j)];
+      m.w = (s.experiment & 2) ? 1.f : __int_as_float(ring[RING + at]);
     };
     if (total > 0) stage(0, mc, off_c);
     for (int jb = 0; jb < wave_total; jb += SB) {
@@ -273,6 +452,8 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_spmm_walk_f32(
         mc = mn; off_c = off_n;
       }
     }
+    seg_base += (total + kFeedChunk - 1) / kFeedChunk;
+    lds_st(feed_done + g_in_blk, seg_base);
     row_change(-1);      // the last row becomes the pending one ...
     finish_pending();    // ... and is folded in
     pacer.signal_upto((r + 1) * s.steps);

@@ -724,7 +724,12 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   std::lock_guard<std::mutex> lk(*mu);
   for (auto& s : *vec)
     if (s.W == W && s.win_cols == win_cols && s.T == T) { *out = &s; return GRAPHOP_OK; }
-  GO_CHECK_ARG(vec->size() < 16, "plan_get_sweep: too many window geometries for one plan");
+  *out = nullptr;
+  // A geometry depends on the row width, the pass type and the tuning: one graph used at many widths
+  // must not grow without bound (every geometry keeps window tables and up to kMaxDealt id copies).
+  // At the cap the caller falls back to the chunk drivers for the new geometry; nothing is evicted
+  // (launches on other streams may still read the existing ones).
+  if (vec->size() >= 16) return GRAPHOP_OK;
   {
     const int rc_cap = check_not_capturing(st, "building the column-window structure of a plan");
     if (rc_cap != GRAPHOP_OK) return rc_cap;

@@ -99,6 +99,9 @@ GRAPHOP_API int graphop_tune(const char* key, int value);
 /* Every knob back to its default (the value at library load: built-in, or GRAPHOP_<KEY> from the
  * environment).  Tests that turn knobs restore them with this, never with literals. */
 GRAPHOP_API int graphop_tune_reset(void);
+/* Device bytes currently held through the library's allocator hook / hipMalloc: plans, their window
+ * structures and id layouts, setup temporaries.  What a binding's plan cache budgets against. */
+GRAPHOP_API int64_t graphop_memory_bytes(void);
 
 /* ---- device memory of plans ------------------------------------------------------------------
  * Plans own device arrays (per orientation: 8 B per chunk, 4-8 B per edge of 32-bit mirrors, and

@@ -18,8 +18,8 @@ WALK_KERNELS = {"k_sddmm_walk_f32", "k_spmm_walk_f32"}
 @pytest.fixture
 def force_walk():
     _lib.tune_reset()
-    _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 8); _lib.tune("walk_min_bin", 0)
-    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512)
+    _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 8); _lib.tune("walk_window_kb_col", 8); _lib.tune("walk_min_bin", 0)
+    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512); _lib.tune("walk", 7)
     _lib.clear_plan_cache()
     yield
     _lib.tune_reset()
@@ -57,7 +57,7 @@ def test_walk_vs_oracle(dev, force_walk, d, blocks):
 def test_walk_matches_other_drivers_medium(dev, force_walk, drift):
     """Same inputs through the walk, window-owner and chunk drivers: equal within fp32 re-association;
     pacing on and off (results never depend on it)."""
-    _lib.tune("walk_drift", drift); _lib.tune("walk_window_kb", 256); _lib.tune("window_kb", 256)
+    _lib.tune("walk_drift", drift); _lib.tune("walk_window_kb", 256); _lib.tune("walk_window_kb_col", 256); _lib.tune("window_kb", 256)
     g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
     gen = torch.Generator(device=dev).manual_seed(2)
     Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
@@ -81,7 +81,7 @@ def test_walk_rows_longer_than_many_bins(dev, force_walk):
     src = torch.cat([torch.randint(0, n, (40000,), generator=gen), torch.full((20000,), 17)])
     dst = torch.randint(0, n, (60000,), generator=gen)
     g = graphs.graph_from_coo(src, dst, n, n, chunk_size=32)
-    _lib.tune("walk_blocks", 16); _lib.tune("walk_window_kb", 64)
+    _lib.tune("walk_blocks", 16); _lib.tune("walk_window_kb", 64); _lib.tune("walk_window_kb_col", 64)
     inp = rand_inputs(g, 1, 64, seed=3, normal=True)
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
     got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
