@@ -51,6 +51,7 @@ _P = _vp
 _SIGNATURES = {
     "graphop_tune": [ctypes.c_char_p, ctypes.c_int],
     "graphop_tune_reset": [],
+    "graphop_tune_get": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "graphop_profile_enable": [ctypes.c_int],
     "graphop_profile_read": [ctypes.POINTER(ProfileRec), ctypes.c_int],
     "graphop_partition_csr_count": [_P, _c64, _c64, _P, _P],
@@ -84,7 +85,7 @@ _SIGNATURES = {
     "graphop_attention_backward": [ctypes.c_int] + [_P] * 17 + [_c64] * 7 + [_P, _c64, _P, _P, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["graphop_abi_version", "graphop_last_error",
-                                               "graphop_plan_destroy", "graphop_memory_bytes"])
+                                               "graphop_plan_destroy", "graphop_memory_bytes", "graphop_tune_key"])
 
 
 def lib():
@@ -103,6 +104,8 @@ def lib():
         l.graphop_plan_destroy.argtypes = [_vp]
         l.graphop_memory_bytes.restype = ctypes.c_int64
         l.graphop_memory_bytes.argtypes = []
+        l.graphop_tune_key.restype = ctypes.c_char_p
+        l.graphop_tune_key.argtypes = [ctypes.c_int]
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = ctypes.c_int
@@ -404,6 +407,24 @@ def _cpp_ext():
 def tune(key, value):
     """Set a tuning knob (include/graphop_hip.h: graphop_tune)."""
     check(lib().graphop_tune(key.encode(), int(value)))
+
+
+def tune_get(key):
+    """Current value of a tuning knob."""
+    v = ctypes.c_int(0)
+    check(lib().graphop_tune_get(key.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+def tune_snapshot():
+    """{knob: value} of every tuning knob (include/graphop_hip.h: graphop_tune_key / graphop_tune_get)."""
+    out, i = {}, 0
+    while True:
+        k = lib().graphop_tune_key(i)
+        if not k:
+            return out
+        out[k.decode()] = tune_get(k.decode())
+        i += 1
 
 
 def tune_reset():

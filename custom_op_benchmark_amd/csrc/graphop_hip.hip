@@ -445,7 +445,6 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_t
     out->view.drift = t.walk_drift;
     out->view.sync = t.walk_drift > 0 ? wk->sync : nullptr;
     out->view.dbg = nullptr;
-    out->view.experiment = env_int("GRAPHOP_WALK_EXPERIMENT", 0);
     out->blocks = (unsigned)blocks;
     out->lds_bytes = walk_lds_bytes<L, NV>();
     if (!dry_run && out->view.sync &&
@@ -965,15 +964,12 @@ int softmax_forward_stats(int dtype, const i64* row, const i64* indptr, const i6
 
 using namespace graphop;
 
-extern "C" {
-
-int graphop_abi_version(void) { return GRAPHOP_ABI_VERSION; }
-const char* graphop_last_error(void) { return get_error(); }
-
-int graphop_tune(const char* key, int value) {
-  GO_CHECK_ARG(key != nullptr, "tune: key is NULL");
+namespace {
+struct TuneEntry { const char* k; int* p; };
+// every knob of Tuning (host.h), by name
+std::vector<TuneEntry> tune_table() {
   Tuning& t = tuning_mut();
-  struct { const char* k; int* p; } tab[] = {
+  return {
       {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"mall_window_kb", &t.mall_window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
@@ -987,13 +983,39 @@ int graphop_tune(const char* key, int value) {
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
       {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps},
       {"walk_prefetch", &t.walk_prefetch}};
-  for (auto& e : tab)
+}
+}  // namespace
+
+extern "C" {
+
+int graphop_abi_version(void) { return GRAPHOP_ABI_VERSION; }
+const char* graphop_last_error(void) { return get_error(); }
+
+int graphop_tune(const char* key, int value) {
+  GO_CHECK_ARG(key != nullptr, "tune: key is NULL");
+  for (auto& e : tune_table())
     if (strcmp(e.k, key) == 0) {
       *e.p = value;
       return GRAPHOP_OK;
     }
   set_error("tune: unknown key '%s'", key);
   return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
+int graphop_tune_get(const char* key, int* value) {
+  GO_CHECK_ARG(key != nullptr && value != nullptr, "tune_get: NULL pointer");
+  for (auto& e : tune_table())
+    if (strcmp(e.k, key) == 0) {
+      *value = *e.p;
+      return GRAPHOP_OK;
+    }
+  set_error("tune_get: unknown key '%s'", key);
+  return GRAPHOP_ERR_INVALID_ARGUMENT;
+}
+
+const char* graphop_tune_key(int i) {
+  static const std::vector<TuneEntry> tab = tune_table();   // (names only: the pointers are not used)
+  return (i >= 0 && i < (int)tab.size()) ? tab[(size_t)i].k : nullptr;
 }
 
 int64_t graphop_memory_bytes(void) {

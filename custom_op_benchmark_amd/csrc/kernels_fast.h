@@ -430,16 +430,10 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
     m.locate<L>(j < m.total ? j : m.total - 1, nk, e);   // every lane takes part in the shuffles
     if (l < SB && j < m.total) {
       ne = EID_ID ? e : (*(eid32 + e));
-#if defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 8)
-      nsrc = (int)(((unsigned)e * 2654435761u) >> 19);
-#else
       nsrc = (*(idx32 + e));
-#endif
     }
   }
-#if !(defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 4))   // measurement build: A rows not fetched (LDS holds stale rows)
   stage_rows();
-#endif
   // h == 1: the batch's 16 results are stored AFTER the next batch's rows have been requested.
   // vmcnt retires in issue order, so a store issued ahead of those loads would have to be
   // acknowledged (a write to HBM) before their data could be used.
@@ -453,9 +447,6 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
     // dotted like the others and only the final store is masked.
     const int my_e = ne;
     const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
-#if defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 1)   // measurement build: every gather inside one 2 MB region
-    nsrc &= 8191;
-#endif
     const unsigned my_off = OFF32 ? (unsigned)nsrc * (unsigned)(F4 * 16) : (unsigned)nsrc;
     float4 b[SB][NV];
     static_for<SB>([&](auto uc) {
@@ -469,11 +460,9 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
           b[u][v] = reinterpret_cast<const float4*>(B)[(i64)o * F4 + v * L + l];
       }
     });
-#if !(defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 2))   // measurement build: no result stores
     if constexpr (H1) {
       if (prev_e >= 0) y[prev_e] = prev_res;
     }
-#endif
     // ids of the next batch (issued after the row requests so they stay in flight behind them)
     ne = -1;
     {
@@ -482,11 +471,7 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       m.locate<L>(j < m.total ? j : m.total - 1, nk, e);
       if (l < SB && j < m.total) {
         ne = EID_ID ? e : (*(eid32 + e));
-#if defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 8)     // measurement build: ids from registers, no id stream
-        nsrc = (int)(((unsigned)e * 2654435761u) >> 19);
-#else
         nsrc = (*(idx32 + e));
-#endif
       }
     }
     float res = 0.f;
@@ -534,13 +519,9 @@ __device__ __forceinline__ void sddmm_strip(const float4* __restrict__ rowsA, in
       prev_e = l < nb ? my_e : -1;
     }
   }
-#if !(defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 2))
   if constexpr (H1) {
     if (prev_e >= 0) y[prev_e] = prev_res;
   }
-#else
-  if (prev_res == 1234.5f && prev_e >= 0) y[prev_e] = prev_res;   // keep the dot products alive
-#endif
   t_idx.retire();
   if constexpr (!EID_ID) t_eid.retire();
 }
@@ -805,11 +786,7 @@ __device__ __forceinline__ void spmm_strip_staged(Sink&& sink, int lo_l, int n_l
     m.locate<L>(j, p.k, e);
     p.src = ids.id(j);          // slots past the end re-read the last neighbour with weight 0
     p.w = 0.f;
-#if defined(GRAPHOP_MEASURE) && (GRAPHOP_MEASURE & 16)   // measurement build: no weight loads
-    if (live) p.w = 1.0f + (float)e * 0.f;
-#else
     if (live) p.w = w[EID_ID ? e : ids.eid(j)];
-#endif
   };
   Pre p1;
   stage(0, p1);

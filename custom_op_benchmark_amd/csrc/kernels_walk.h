@@ -44,7 +44,6 @@ struct WalkView {
   i64 win_cols;          // ids per column window
   i64 table_bytes;       // bytes of the gathered table (0: the feeder does not touch it ahead)
   int xcd_wgs;           // workgroups per XCD slot (each touches its share of the next window)
-  int experiment;        // measurement variants (WRONG RESULTS): bit 0 every gather inside one 2 MB region, bit 1 no weight loads / result stores
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
 };
 
@@ -427,8 +426,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       const int at = (seg_base * kFeedChunk + jb + l) % RING;
       const int idw = ring[at];
       m.k = (int)((unsigned)idw >> kWalkKShift);
-      off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
-      m.w = (s.experiment & 2) ? 1.f : __int_as_float(ring[RING + at]);
+      off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
+      m.w = __int_as_float(ring[RING + at]);
     };
     if (total > 0) stage(0, mc, off_c);
     for (int jb = 0; jb < wave_total; jb += SB) {
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
         const int idw = ids.id(j);
         const int my_e = (l < nb) ? ids.eid(j) : -1;
         const unsigned my_koff = ((unsigned)idw >> kWalkKShift) * (unsigned)(F4 * 16);
-        const unsigned my_off = (unsigned)(idw & ((s.experiment & 1) ? 8191 : kWalkIdMask)) * (unsigned)(F4 * 16);
+        const unsigned my_off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
         float4 b[SB][NV];
         static_for<SB>([&](auto uc) {
           constexpr int u = decltype(uc)::value;
@@ -538,7 +537,7 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
 #pragma unroll
           for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
         });
-        if (prev_e >= 0 && !(s.experiment & 2)) y[prev_e] = prev_res;   // behind the row requests (vmcnt retires in order)
+        if (prev_e >= 0) y[prev_e] = prev_res;   // behind the row requests (vmcnt retires in order)
         float part[SB];
         static_for<SB>([&](auto uc) {
           constexpr int u = decltype(uc)::value;

@@ -398,21 +398,23 @@ class ShardedAttention:
         h = ds.size(1) if ds.dim() == 2 else 1
         L = _lib.lib()
         with _lib.device_guard(Q.device):
+            # the skipped orientation gets NO plan (NULL): a plan over the empty chunk list would still
+            # validate all E slots and allocate 32-bit mirrors of the slot arrays that no kernel reads
             if col_half:
                 out = torch.empty_like(K_ext)
-                plan_r = _lib.get_plan(er, ep, g.eid_r, g.indices_r, K_ext.size(0))
-                plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, Q.size(0))
+                plan_r = None
+                plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, Q.size(0)).handle
                 row, ptr_r, col, ptr_c, dA, dB = er, ep, g.col, g.ptr_c, None, out
             else:
                 out = torch.empty_like(Q)
-                plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, K_ext.size(0))
-                plan_c = _lib.get_plan(er, ep, g.eid_c, g.indices_c, Q.size(0))
+                plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, K_ext.size(0)).handle
+                plan_c = None
                 row, ptr_r, col, ptr_c, dA, dB = g.row, g.ptr_r, er, ep, out, None
             _lib.check(L.graphop_maskedmm_csr_backward(
                 _lib.dtype_code(Q), _lib.ptr(row), _lib.ptr(ptr_r), _lib.ptr(g.eid_r), _lib.ptr(g.indices_r),
                 _lib.ptr(col), _lib.ptr(ptr_c), _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(Q), _lib.ptr(K_ext),
                 _lib.ptr(ds), _lib.ptr(dA), _lib.ptr(dB), row.size(0), col.size(0), g.eid_r.size(0),
-                Q.size(0), K_ext.size(0), h, Q.size(-1), plan_r.handle, plan_c.handle, _lib.stream_of(Q)))
+                Q.size(0), K_ext.size(0), h, Q.size(-1), plan_r, plan_c, _lib.stream_of(Q)))
         return out
 
     def _empty_chunks(self):

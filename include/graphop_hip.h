@@ -99,6 +99,9 @@ GRAPHOP_API int graphop_tune(const char* key, int value);
 /* Every knob back to its default (the value at library load: built-in, or GRAPHOP_<KEY> from the
  * environment).  Tests that turn knobs restore them with this, never with literals. */
 GRAPHOP_API int graphop_tune_reset(void);
+/* Read a knob; enumerate the knob names (i = 0, 1, ...; NULL past the last one). */
+GRAPHOP_API int graphop_tune_get(const char* key, int* value);
+GRAPHOP_API const char* graphop_tune_key(int i);
 /* Device bytes currently held through the library's allocator hook / hipMalloc: plans, their window
  * structures and id layouts, setup temporaries.  What a binding's plan cache budgets against. */
 GRAPHOP_API int64_t graphop_memory_bytes(void);

@@ -72,8 +72,7 @@ def test_sharded_hip_step_window_drivers(dev, world):
         _check(g, want, parts)
     finally:
         _lib.profile_enable(False)
-        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
-        _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 def test_pack_and_scatter_add_kernels(dev):
@@ -88,3 +87,35 @@ def test_pack_and_scatter_add_kernels(dev):
         _lib.scatter_add_rows(acc, idx, got)
         torch.testing.assert_close(acc, want, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6)
     assert _lib.gather_rows(X, idx[:0]).shape[0] == 0
+
+
+def test_two_shards_at_scale_vs_cpu_path(dev):
+    """World 2 on one GPU (LocalGroup: real device-to-device halo exchanges) at 2.5e7 edges and the
+    DEFAULT kernel geometry -- the shards' local graphs are large enough for the window and walk
+    drivers -- against the stock-PyTorch CPU path on the global graph."""
+    from custom_op_benchmark_amd import graphs
+    from oracle import torch_path
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    N, E, d = 60000, 25_000_000, 64
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=11, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(12)
+    Q, K, V, dO = (torch.randn(N, d, device=dev, generator=gen) / 8 for _ in range(4))
+    inp = dict(Q=Q, K=K, V=V, dO=dO)
+
+    def shard(rank, handle):
+        sh = ShardedAttention.from_global_coo(g.src, g.dst, N, rank, 2, dev, chunk_size=32, group=handle)
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        r = sh.step(*(inp[k][lo:hi].contiguous() for k in ("Q", "K", "V", "dO")))
+        torch.cuda.synchronize()
+        return dict(lo=lo, hi=hi, n_halo=sh.n_halo, **{k: r[k].detach() for k in ("o", "dQ", "dK", "dV")})
+    _lib.profile_enable(True)
+    parts = run_local_shards(2, shard)
+    kernels = {r.get("kernel") for r in _lib.profile_read().values()}
+    _lib.profile_enable(False)
+    assert "k_spmm_walk_f32" in kernels or "k_spmm_wown_staged_f32" in kernels, kernels
+    assert all(z["n_halo"] > 0 for z in parts)
+    o0, dQ0, dK0, dV0 = torch_path.attention_step_blocked(g.src.cpu(), g.dst.cpu(), g.indptr_r.cpu(), Q.cpu(), K.cpu(),
+                                                          V.cpu(), dO.cpu(), N, rows_per_block=2048)
+    for name, want in (("o", o0), ("dQ", dQ0), ("dK", dK0), ("dV", dV0)):
+        got = torch.cat([z[name] for z in parts]).cpu()
+        torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5, msg=lambda m: name + ": " + m)

@@ -66,11 +66,7 @@ def force_sweep():
     _lib.tune("attn_max_d", 1024)          # by default the fused window passes are only chosen up to d = 64
     _lib.clear_plan_cache()
     yield
-    _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0); _lib.tune("max_windows", 128)
-    _lib.tune("sweep_bpc", 3); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
-    _lib.tune("attn_bpc", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2); _lib.tune("staged_ids", 7)
-    _lib.tune("attn_max_d", 64)
-    _lib.clear_plan_cache()
+    _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 @pytest.mark.parametrize("h,d", [(1, 64), (1, 16), (8, 16), (2, 32), (3, 5), (1, 128)])
@@ -148,7 +144,7 @@ def test_fused_chunk_driver_passes_vs_oracle(dev, d, chunk_size, rows_sorted):
         _lib.tune("attn_rows", 0); _lib.clear_plan_cache()
         assert not ({"attn_rows_row", "attn_rows_col"} & prof_tags(step))
     finally:
-        _lib.tune("attn_rows", -1); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 def test_fused_selection_follows_the_measured_rules(dev):
@@ -194,7 +190,7 @@ def test_fused_matches_unfused_medium_powerlaw(dev):
         for key, ref in (("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
             torch.testing.assert_close(got[key], ref, rtol=2e-4, atol=2e-5)
     finally:
-        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 def test_fused_uniform_inputs_and_large_scores(dev, force_sweep):

@@ -271,7 +271,7 @@ def test_interleaved_empty_chunks(dev):
         w = torch.rand(9)
         o = ops.vector_spmm_forward(row.to(dev), ptr.to(dev), eid.to(dev), dst.to(dev), w.to(dev), K.to(dev))
     finally:
-        _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
     close(got, want)
     close(o[:3], oracle.vector_spmm_forward(row, ptr, eid, dst, w, K)[:3])
 
@@ -367,10 +367,7 @@ def force_sweep():
     _lib.tune("max_windows", 128); _lib.tune("sweep_min_granule", 0)
     _lib.clear_plan_cache()
     yield
-    _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
-    _lib.tune("sweep_bpc", 3); _lib.tune("sweep_k", 0); _lib.tune("sweep_min_granule", 4)
-    _lib.tune("sweep_mode", 1)
-    _lib.clear_plan_cache()
+    _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -421,7 +418,7 @@ def test_id_staging_on_and_off_vs_oracle(dev, force_sweep, d, staged):
         else:
             assert {"k_sddmm_wown_f32", "k_spmm_wown_f32"} <= kernels, kernels
     finally:
-        _lib.tune("staged_ids", 7); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 @pytest.mark.parametrize("k", [1, 4])
@@ -460,7 +457,7 @@ def test_staged_strips_at_segment_boundaries(dev, force_sweep, deg, k):
         for key, grad in (("dQ", q.grad), ("dK", kk.grad), ("dV", v.grad)):
             close(grad, want[key])
     finally:
-        _lib.tune("sweep_k", 0); _lib.tune("attn_k", 0); _lib.tune("attn_window_scale", 2); _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -476,7 +473,7 @@ def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
     try:
         ch = hip_step(g, Q, K, V, dO)
     finally:
-        _lib.tune("sweep", 1)
+        _lib.tune_reset(); _lib.clear_plan_cache()
     # (the strips reduce a batch of 16 dots by a transpose-reduce, the chunk driver slot by slot:
     # same products, different summation tree)
     for k in ("s", "a", "o", "dQ", "dK", "dV"):
@@ -515,7 +512,7 @@ def test_scalar_transpose_path_matches(dev, force_sweep):
     try:
         tr = hip_step(g, Q, K, V, dO)
     finally:
-        _lib.tune("transpose_scalars", 0)
+        _lib.tune_reset(); _lib.clear_plan_cache()
     for k in ("dK", "dV", "dQ", "o"):
         torch.testing.assert_close(tr[k], base[k], rtol=1e-4, atol=1e-5)
 
@@ -590,8 +587,7 @@ def test_block_dense_drivers_vs_oracle(dev, l, h, d):
         _lib.tune("dense_blocks", 0)
         ref = hip_step(gd, *args)
     finally:
-        _lib.tune("dense_blocks", 1); _lib.tune("dense_detect_min_fill", 10); _lib.tune("dense_min_fill", 40)
-        _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
     for k in ("s", "a", "o", "dQ", "dK", "dV"):
         torch.testing.assert_close(got[k], ref[k], rtol=1e-4, atol=1e-5)
 
@@ -624,8 +620,7 @@ def test_block_dense_long_runs_and_ragged_blocks(dev):
             for k in ("s", "a", "o", "dQ", "dK", "dV"):
                 close(got[k], want[k])
     finally:
-        _lib.tune("dense_min_fill", 40); _lib.tune("dense_detect_min_fill", 10)
-        _lib.clear_plan_cache()
+        _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 def test_block_dense_not_selected_on_irregular_graphs(dev):

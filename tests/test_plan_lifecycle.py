@@ -17,8 +17,7 @@ def small_windows():
     _lib.tune("sweep_min_kb", 0); _lib.tune("window_kb", 8); _lib.tune("vrow_t", 64)
     _lib.tune("sweep_min_granule", 0); _lib.clear_plan_cache()
     yield
-    _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0)
-    _lib.tune("sweep_min_granule", 4); _lib.clear_plan_cache()
+    _lib.tune_reset(); _lib.clear_plan_cache()
 
 
 def _inputs(dev, n, d, seed=1):

@@ -12,8 +12,31 @@ import torch
 from custom_op_benchmark_amd import _lib, functions, graphs
 from custom_op_benchmark_amd import graphop as ops
 from oracle import torch_path
+from conftest import DEFAULT_KNOBS
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def default_knobs():
+    """Every test of this file runs at the library's default geometry: the knobs are reset (never
+    restored from literals) and compared with the snapshot taken when the library was loaded."""
+    _lib.tune_reset()
+    _lib.clear_plan_cache()
+    assert _lib.tune_snapshot() == DEFAULT_KNOBS
+    yield
+    _lib.tune_reset()
+
+
+def test_default_geometry_is_the_librarys(dev):
+    """tune_reset() restores Tuning()'s values whatever earlier tests left behind."""
+    for k in DEFAULT_KNOBS:
+        _lib.tune(k, 12345)
+    assert _lib.tune_get("window_kb") == 12345
+    _lib.tune_reset()
+    assert _lib.tune_snapshot() == DEFAULT_KNOBS
+    with pytest.raises(RuntimeError, match="unknown key"):
+        _lib.tune_get("no_such_knob")
 
 
 def test_default_geometry_medium_graph_vs_cpu_path(dev):
@@ -28,7 +51,8 @@ def test_default_geometry_medium_graph_vs_cpu_path(dev):
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     # the headline drivers ran, at the default geometry
-    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_staged_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_wown_staged_f32", prof
+    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_staged_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_walk_f32" \
+        and prof["spmm_fwd"]["kernel"] == "k_spmm_walk_f32", prof
     o0, dQ0, dK0, dV0 = torch_path.attention_step_blocked(g.src.cpu(), g.dst.cpu(), g.indptr_r.cpu(), Q.cpu(), K.cpu(),
                                                           V.cpu(), dO.cpu(), N, rows_per_block=2048)
     tol = dict(rtol=2e-4, atol=2e-5)
@@ -122,3 +146,72 @@ def test_products_scale_properties(dev):
     dsm = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, torch.full_like(a, 3.0))
     assert float(dsm.abs().max()) < 1e-4
     ops.release(g)
+
+
+# ---- BASELINE.json configs 4 and 5: one shard of the 8-way node partition, real halo ids ----------------
+def _shard_property_battery(dev, sh, d):
+    """Size-independent properties of every op on a shard's n_own x (n_own + n_halo) local graph."""
+    g = sh.graph
+    E, n_q, n_k = g.n_edges, g.n_src, g.n_dst
+    a4, a8 = (g.row, g.ptr_r, g.eid_r, g.indices_r), g.csr_args()
+    deg = (g.indptr_r[1:] - g.indptr_r[:-1]).float()
+    ones_q = torch.ones(n_q, d, device=dev); ones_k = torch.ones(n_k, d, device=dev)
+    s1 = ops.maskedmm_csr_forward(*a4, ones_q, ones_k)
+    assert s1.shape == (E,) and torch.equal(s1, torch.full_like(s1, float(d)))
+    o1 = ops.vector_spmm_forward(*a4, torch.ones(E, device=dev), ones_k)
+    assert o1.shape == (n_k, d)                       # the reference's zeros_like(x) output (graphop_kernel.cu:527)
+    torch.testing.assert_close(o1[:n_q, 17], deg, rtol=1e-5, atol=0)
+    assert float(o1[n_q:].abs().max()) == 0.0
+    del s1, o1, ones_q, ones_k
+    gen = torch.Generator(device=dev).manual_seed(1)
+    Q = torch.rand(n_q, d, device=dev, generator=gen); K = torch.rand(n_k, d, device=dev, generator=gen)
+    s = ops.maskedmm_csr_forward(*a4, Q, K)
+    assert torch.equal(s, ops.maskedmm_csr_forward(*a4, Q, K))                      # deterministic
+    torch.testing.assert_close(ops.maskedmm_csr_forward(*a4, Q * 2, K), 2 * s, rtol=1e-6, atol=0)
+    a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+    rowsum = torch.zeros(n_q, device=dev, dtype=torch.float64).index_add_(0, g.src, a.double())
+    nz = deg > 0
+    torch.testing.assert_close(rowsum[nz], torch.ones_like(rowsum[nz]), rtol=0, atol=1e-5)
+    del rowsum
+    V = torch.rand(n_k, d, device=dev, generator=gen); G = torch.rand(n_k, d, device=dev, generator=gen)
+    G[n_q:] = 0                                       # rows the forward never writes carry no gradient
+    o = ops.vector_spmm_forward(*a4, a, V)
+    da, dV = ops.vector_spmm_backward(*a8, a, G, V)
+    lhs = (o.double() * G.double()).sum()
+    torch.testing.assert_close((a.double() * da.double()).sum(), lhs, rtol=1e-6, atol=0)
+    torch.testing.assert_close((V.double() * dV.double()).sum(), lhs, rtol=1e-6, atol=0)
+    del o, dV, V, G
+    dQ, dK = ops.maskedmm_csr_backward(*a8, Q, K, da)
+    ref = (s.double() * da.double()).sum()                     # <SDDMM(Q,K), da> = <Q, dQ> = <K, dK>
+    torch.testing.assert_close((Q.double() * dQ.double()).sum(), ref, rtol=1e-6, atol=0)
+    torch.testing.assert_close((K.double() * dK.double()).sum(), ref, rtol=1e-6, atol=0)
+    dsm = ops.sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, torch.full_like(a, 3.0))
+    assert float(dsm.abs().max()) < 1e-4
+    ops.release(g)
+
+
+def test_papers100m_shard_properties(dev):
+    """BASELINE config 4: rank 0 of 8 of the papers100M-shaped weak-scaling graph (13.9 M own nodes, 202 M
+    edges, d = 128), columns renumbered own-first-then-halo exactly as the sharded step sees them."""
+    from custom_op_benchmark_amd.dist import ShardedAttention
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 150 << 30:
+        pytest.skip("needs ~120 GB of free HBM")
+    n_per_rank, e_per_rank = 111_059_956 // 8, 1_615_685_872 // 8
+    sh = ShardedAttention.synthetic(n_per_rank, e_per_rank, 8, 0, dev, alpha=0.5, seed=0, timing_only=True, cut=0.1)
+    assert sh.n_halo > 0 and sh.graph.n_dst == sh.n_own + sh.n_halo
+    assert int(sh.halo_ids.min()) >= n_per_rank                     # rank 0: every halo node lives on another rank
+    _shard_property_battery(dev, sh, 128)
+
+
+def test_rmat25_shard_properties(dev):
+    """BASELINE config 5: rank 0 of 8 of the R-MAT scale-25 graph (the densest node range: rows of 10^5-10^6
+    slots), d = 256."""
+    from custom_op_benchmark_amd.dist import ShardedAttention
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 200 << 30:
+        pytest.skip("needs ~170 GB of free HBM")
+    sh = ShardedAttention.synthetic_rmat(25, (1 << 30) // 8, 8, 0, dev, seed=0, timing_only=True)
+    deg = sh.graph.indptr_r[1:] - sh.graph.indptr_r[:-1]
+    assert int(deg.max()) > 100_000, int(deg.max())
+    _shard_property_battery(dev, sh, 256)
