@@ -127,10 +127,12 @@ struct Walk {
   int* bin_pos = nullptr; // [bins * GW + 1] first slot of every lane group's run
   int* bin_rows = nullptr;// [bins * kWalkK * GW] row id | (shared << 31), -1 = unused
   int* bin_cum = nullptr; // [bins * GW] slots in every lane group's run
-  int* sync = nullptr;    // pacer counters of the walk kernels (zeroed before every launch)
-  long long sync_ints = 0;
+  int* sync = nullptr;    // kWalkSyncRing sets of pacer counters of the walk kernels (a set is zeroed before the launch that takes it)
+  long long sync_ints = 0;  // ints per set
+  unsigned sync_next = 0;   // next set (taken under the plan's sweep mutex)
   int max_steps = 0;      // pacing steps per round the counters are sized for
 };
+constexpr int kWalkSyncRing = 4;
 constexpr int kWalkK = 14;        // rows per lane group: 14 x 256 B x 16 lane groups + the id rings = 2 workgroups per CU
 constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax

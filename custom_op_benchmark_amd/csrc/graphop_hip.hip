@@ -126,6 +126,7 @@ void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
 int plan_get_walk(graphop_plan*, int, i64, int, int, int, hipStream_t, const Walk**);
+int* plan_take_walk_sync(graphop_plan*, const Walk*);
 
 Tuning& tuning_mut() {
   static Tuning t;
@@ -443,7 +444,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_t
     out->view.table_bytes = t.walk_prefetch ? table_bytes : 0;
     out->view.xcd_wgs = (int)(blocks / slots);
     out->view.drift = t.walk_drift;
-    out->view.sync = t.walk_drift > 0 ? wk->sync : nullptr;
+    out->view.sync = (t.walk_drift > 0 && !dry_run) ? plan_take_walk_sync(const_cast<graphop_plan*>(plan), wk) : nullptr;
     out->view.dbg = nullptr;
     out->blocks = (unsigned)blocks;
     out->lds_bytes = walk_lds_bytes<L, NV>();
@@ -1147,6 +1148,19 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
     rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/false, &o);
     o.staged = spmm_staged(L, NV, h, n_table_rows);
     if (rc >= 0) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &o);
+    // walk layouts of the passes that would take them (kernels_walk.h)
+    if constexpr (NV == 1 && L >= 16) {
+      WalkLaunch wl;
+      const int bit = plan->info.eid_identity ? 2 : 4;
+      if (rc >= 0 && h == 1 && (tuning().walk & bit)) {
+        const int r2 = choose_walk<L, NV>(plan, n_table_rows, 1, kWalkWorkers, 1, st, &wl, /*dry_run=*/true);
+        if (r2 < 0) rc = r2;
+      }
+      if (rc >= 0 && h == 1 && (tuning().walk & 1)) {
+        const int r2 = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kFastBlock, kWalkBpc, st, &wl, /*dry_run=*/true);
+        if (r2 < 0) rc = r2;
+      }
+    }
   });
   if (rc < 0) return -rc;
   if (fused && h == 1) {

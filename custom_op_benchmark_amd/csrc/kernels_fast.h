@@ -607,8 +607,24 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
   IdStage<L, 1> ids;
   ids.init(ids_w, nullptr, pos0, idbuf, l, m.total);
   stage_rows();
-  float prev_res = 0.f;
-  int prev_e = -1;
+  // The results of kStoreBatch batches are stored together, behind the row requests of the next batch:
+  // vmcnt retires in issue order and a store is acknowledged later than an L2-hit load returns, so
+  // every store instruction between two batches of row requests delays the rows behind it once;
+  // kStoreBatch stores issued back to back share that delay.
+  constexpr int kStoreBatch = 4;
+  float held_res[kStoreBatch];
+  int held_e[kStoreBatch];
+#pragma unroll
+  for (int q = 0; q < kStoreBatch; ++q) { held_res[q] = 0.f; held_e[q] = -1; }
+  int n_held = 0;   // group-uniform
+  auto flush_results = [&]() {
+#pragma unroll
+    for (int q = 0; q < kStoreBatch; ++q) {
+      if (held_e[q] >= 0) y[held_e[q]] = held_res[q];
+      held_e[q] = -1;
+    }
+    n_held = 0;
+  };
   const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
   for (int jb = 0; jb < m.total; jb += SB) {
     const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
@@ -627,7 +643,7 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
 #pragma unroll
       for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
     });
-    if (prev_e >= 0) y[prev_e] = prev_res;
+    if (n_held == kStoreBatch) flush_results();
     float part[SB];
     static_for<SB>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
@@ -640,10 +656,13 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
       for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
       part[u] = p;
     });
-    prev_res = group_dots_to_owner<L, SB>(part, l);
-    prev_e = my_e;
+    const float res = group_dots_to_owner<L, SB>(part, l);
+#pragma unroll
+    for (int q = 0; q < kStoreBatch; ++q)
+      if (q == n_held) { held_res[q] = res; held_e[q] = my_e; }
+    ++n_held;
   }
-  if (prev_e >= 0) y[prev_e] = prev_res;
+  flush_results();
 }
 
 // `sink(k, acc)` receives the finished partial sum of granule k (group-uniform call).

@@ -784,6 +784,14 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   return GRAPHOP_OK;
 }
 
+// Every walk launch takes the next of kWalkSyncRing sets of pacer counters, so launches of one plan that
+// overlap on different streams do not zero each other's counters (a set is reused four launches later).
+int* plan_take_walk_sync(graphop_plan* p, const Walk* wk) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  Walk* w = const_cast<Walk*>(wk);
+  return w->sync + (size_t)(w->sync_next++ % kWalkSyncRing) * (size_t)w->sync_ints;
+}
+
 int* plan_take_queue(graphop_plan* p, const Sweep* sw) {
   std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
   Sweep* s = const_cast<Sweep*>(sw);
@@ -915,13 +923,13 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
   wk.n_slots = (i64)total + 1024;   // slack: a bin's last id segment is fetched whole
   wk.max_steps = 8 * W < 1024 ? 8 * W : 1024;   // pacing steps per round (kernels_walk.h: WalkView::steps)
   const i64 steps = rounds * wk.max_steps;
-  wk.sync_ints = 64LL * (8 + 16 * steps);
+  wk.sync_ints = 64LL * (8 + 16 * steps);   // one set of pacer counters; kWalkSyncRing of them are allocated
   if (go_malloc((void**)&wk.ids, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
       go_malloc((void**)&wk.widx, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
       go_malloc((void**)&wk.bin_pos, sizeof(int) * (size_t)(gbins + 1), st) != hipSuccess ||
       go_malloc((void**)&wk.bin_rows, sizeof(int) * (size_t)(bins * kmax), st) != hipSuccess ||
       go_malloc((void**)&wk.bin_cum, sizeof(int) * (size_t)gbins, st) != hipSuccess ||
-      go_malloc((void**)&wk.sync, sizeof(int) * (size_t)wk.sync_ints, st) != hipSuccess) {
+      go_malloc((void**)&wk.sync, sizeof(int) * (size_t)wk.sync_ints * kWalkSyncRing, st) != hipSuccess) {
     go_free(wk.ids); go_free(wk.widx); go_free(wk.bin_pos); go_free(wk.bin_rows); go_free(wk.bin_cum); go_free(wk.sync);
     set_error("plan_get_walk: out of device memory for %lld slots", (long long)wk.n_slots);
     return GRAPHOP_ERR_HIP;

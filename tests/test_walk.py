@@ -87,3 +87,37 @@ def test_walk_rows_longer_than_many_bins(dev, force_walk):
     got = hip_step(g.to(dev), *(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
     for k in ("s", "a", "o", "dQ", "dK", "dV"):
         close(got[k], want[k])
+
+
+def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk):
+    """graphop.prepare builds the walk layouts too: the step afterwards allocates nothing, so it captures
+    into a HIP graph, and the replay (walk kernels with their pacer counters zeroed inside the graph)
+    reproduces the eager result."""
+    from custom_op_benchmark_amd import graphop as ops
+    _lib.tune("walk_blocks", 16)
+    g = random_graph(1500, 1500, 15000, seed=13, chunk_size=32, hub=900).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    Q, K, V, dO = (torch.randn(1500, 64, device=dev, generator=gen) / 8 for _ in range(4))
+    ops.prepare(g, h=1, d=64, fused=False)
+    held = _lib.plan_memory_bytes()
+    want = hip_step(g, Q, K, V, dO)
+    assert _lib.plan_memory_bytes() == held            # the eager step built nothing after prepare
+    assert WALK_KERNELS <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
+    a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+    s = ops.maskedmm_csr_forward(*a4, Q, K)
+    a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.vector_spmm_forward(*a4, a, V)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o = ops.vector_spmm_forward(*a4, a, V)
+        dQ, dK = ops.maskedmm_csr_backward(*g.csr_args(), Q, K, a)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o, want["o"], rtol=1e-5, atol=1e-6)
+    dQ2, dK2 = ops.maskedmm_csr_backward(*g.csr_args(), Q, K, a)
+    torch.testing.assert_close(dQ, dQ2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dK, dK2, rtol=1e-5, atol=1e-6)
