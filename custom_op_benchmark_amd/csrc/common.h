@@ -131,9 +131,10 @@ struct Walk {
   long long sync_ints = 0;  // ints per set
   unsigned sync_next = 0;   // next set (taken under the plan's sweep mutex)
   int max_steps = 0;      // pacing steps per round the counters are sized for
+  long long longest_run = 0;  // slots in the longest lane-group run (pacing steps are cut from it)
 };
 constexpr int kWalkSyncRing = 4;
-constexpr int kWalkK = 14;        // rows per lane group: 14 x 256 B x 16 lane groups + the id rings = 2 workgroups per CU
+constexpr int kWalkK = 15;        // rows per lane group: 15 x 256 B + a 1 KB ring, x 32 lane groups = 152 KB of a CU's 160 KB LDS
 constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)

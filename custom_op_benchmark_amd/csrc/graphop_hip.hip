@@ -429,20 +429,12 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_t
     out->view.bin_rows = wk->bin_rows; out->view.bin_cum = wk->bin_cum;
     out->view.W = wk->W; out->view.groups = wk->groups; out->view.rounds = wk->rounds;
     out->view.xcd_slots = slots;
-    // pacing steps: equal slot counts; every bin holds n_edges / bins slots, give or take one per window
     {
-      constexpr int SB = StripCfg<L, NV>::SB;
-      const i64 runs = (i64)wk->groups * wk->rounds;   // one per lane group and round
-      const i64 longest = ceil_div(pi.n_edges, runs) + 2 * wk->W + 1;
       i64 steps = (i64)wk->W * (t.walk_steps > 0 ? t.walk_steps : 1);
       if (steps > wk->max_steps) steps = wk->max_steps;
-      if (steps < 1) steps = 1;
-      out->view.steps = (int)steps;
-      out->view.step_len = (int)(ceil_div(ceil_div(longest, steps), SB) * SB);
+      if (steps > wk->longest_run / 16) steps = wk->longest_run / 16;   // at least a batch per step
+      out->view.steps = (int)(steps < 1 ? 1 : steps);
     }
-    out->view.win_cols = wk->win_cols;
-    out->view.table_bytes = t.walk_prefetch ? table_bytes : 0;
-    out->view.xcd_wgs = (int)(blocks / slots);
     out->view.drift = t.walk_drift;
     out->view.sync = (t.walk_drift > 0 && !dry_run) ? plan_take_walk_sync(const_cast<graphop_plan*>(plan), wk) : nullptr;
     out->view.dbg = nullptr;
@@ -982,8 +974,7 @@ std::vector<TuneEntry> tune_table() {
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
       {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
-      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps},
-      {"walk_prefetch", &t.walk_prefetch}};
+      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps}};
 }
 }  // namespace
 

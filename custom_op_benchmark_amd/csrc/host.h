@@ -55,7 +55,6 @@ struct Tuning {
                           // share the L2 with the window (Reddit shape: 2.72 ms at 4 MB, 2.25 at 2 MB; row-major 1.71 / 1.78)
   int walk_drift;         // pacing steps a wave may run ahead of the slowest wave of its XCD (0 = free-running)
   int walk_steps;         // pacing steps per column window
-  int walk_prefetch;      // the feeder wave of the SpMM-type walk kernel touches the next window's share of the table
   int walk_min_bin;       // fewest slots per (lane group, round) bin for the walk drivers to be chosen
   int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
   int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
@@ -92,7 +91,6 @@ struct Tuning {
     walk_window_kb_col = env_int("GRAPHOP_WALK_WINDOW_KB_COL", 2048);
     walk_drift = env_int("GRAPHOP_WALK_DRIFT", 2);
     walk_steps = env_int("GRAPHOP_WALK_STEPS", 1);
-    walk_prefetch = env_int("GRAPHOP_WALK_PREFETCH", 0);   // measured on the Reddit shape: 1.78 -> 2.05 ms per row-major pass with it
     walk_min_bin = env_int("GRAPHOP_WALK_MIN_BIN", 1024);
     walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);

@@ -37,13 +37,9 @@ struct WalkView {
   const int* bin_cum;    // [bins * GW] slots in every lane group's run
   int* sync;             // pacer counters, zero at launch (nullptr = free-running)
   int W, groups, rounds;
-  int steps;             // pacing steps per round: step = (first slot of the batch) / step_len, the same for every bin
-  int step_len;          // slots per pacing step (multiple of the batch size; steps * step_len >= the longest bin)
+  int steps;             // pacing steps per round: a wave's step = position in its longest run / (that run's length / steps)
   int drift;             // a wave may start step s only once every wave of its XCD has left step s - drift
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
-  i64 win_cols;          // ids per column window
-  i64 table_bytes;       // bytes of the gathered table (0: the feeder does not touch it ahead)
-  int xcd_wgs;           // workgroups per XCD slot (each touches its share of the next window)
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
 };
 
@@ -174,8 +170,9 @@ __host__ __device__ constexpr size_t walk_lds_bytes() {
 // it for a trip to the Infinity Cache or HBM.  Here the worker waves issue row requests and nothing
 // else: the feeder waves of the workgroup read the lane groups' (id, edge id) runs a chunk of
 // kFeedChunk slots at a time, gathers the weights, and leaves ids and weights in a small LDS ring per
-// lane group (kFeedRing chunks); it also touches the next column window's share of the table when
-// its lane group 0 enters a window, so the first gather of a row in a round finds it in L2.
+// lane group (kFeedRing chunks).  (Touching the next column window's share of the table ahead of the
+// gathers was tried from the feeders and measured slower at every window size, 1.78 -> 2.0 ms per pass:
+// two windows and the streams do not fit a 4 MiB L2 together.)
 // Hand-over per (lane group, chunk) through two LDS words: `ready` = chunks written by the
 // feeder, `done` = chunks the lane group has finished reading (LDS operations of a wave execute in
 // order; the words are accessed with relaxed workgroup-scope atomics between compiler barriers).
@@ -237,8 +234,6 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     int chunk_base[NG];                               // chunks of earlier rounds (wave-uniform)
 #pragma unroll
     for (int g = 0; g < NG; ++g) chunk_base[g] = 0;
-    int last_win = -1;
-    int pf[4] = {0, 0, 0, 0};
     long long t_space = 0;
     for (int r = 0; r < s.rounds; ++r) {
       int pos0[NG], total[NG], nchunk[NG], c[NG];
@@ -300,24 +295,6 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
           if (s.dbg) t_space += __builtin_amdgcn_s_memtime() - t0;
           continue;
         }
-        // the next window's share of the table -> this XCD's L2 (speed only): when lane group 0 enters a window
-        if ((adv & 1) && g0 == 0 && s.table_bytes > 0) {
-          const int win = (int)((i64)__builtin_amdgcn_readfirstlane(idW[0] & kWalkIdMask) / s.win_cols);
-          if (win != last_win) {
-            last_win = win;
-            asm volatile("; prefetched %0 %1 %2 %3" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
-            const i64 wb = (i64)s.win_cols * (F4 * 16);                 // bytes per window
-            const i64 share = ((wb / s.xcd_wgs) + 63) & ~(i64)63;       // this workgroup's share
-            const i64 lo = (i64)(win + 1) * wb + (i64)(blockIdx.x / s.xcd_slots) * share;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pf[q] = 0;
-            for (i64 o = (i64)h * 64, q = 0; o < share && q < 16; o += kWave * 64, ++q) {
-              const i64 at2 = lo + o;
-              if (at2 + 4 <= s.table_bytes && at2 < (i64)(win + 2) * wb)
-                pf[q & 3] += *reinterpret_cast<const int*>(reinterpret_cast<const char*>(X) + at2);
-            }
-          }
-        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           if (!((adv >> g) & 1)) continue;
@@ -335,7 +312,6 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
       for (int g = 0; g < NG; ++g) chunk_base[g] += nchunk[g];
     }
-    asm volatile("; prefetched %0 %1 %2 %3" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
     if (s.dbg && h == 0 && g0 == 0) {
       long long* d = s.dbg + (long long)gridDim.x * 32 + (long long)blockIdx.x * 2;
       d[0] = __builtin_amdgcn_s_memtime() - t_start; d[1] = t_space;
@@ -359,6 +335,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
       for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int wave_total = wave_max_int<L>(total);
+    // pacing steps = equal shares of this wave's longest run: equal positions in the runs mean nearly equal columns
+    const int step_len = (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB > 0 ? (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB : SB;
     float4 acc[NV], pend_acc[NV], pend_rd[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -434,10 +412,10 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       // pacing by progress: all bins hold the same number of slots (+- W), so equal positions in their
       // runs mean nearly equal columns
       if (jb >= next_step_at) {   // wave-uniform
-        const int step = r * s.steps + jb / s.step_len;
+        const int step = r * s.steps + jb / step_len;
         pacer.signal_upto(step);
         pacer.wait_enter(step, step);
-        next_step_at = (jb / s.step_len + 1) * s.step_len;
+        next_step_at = (jb / step_len + 1) * step_len;
       }
       if (jb < total) {
         static_for<SB>([&](auto uc) {
@@ -504,6 +482,8 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
     const int my_row = lw < KW ? s.bin_rows[tb * KW + lw] : -1;
     int next_step_at = 0;
     const int wave_total = wave_max_int<L>(total);
+    // pacing steps = equal shares of this wave's longest run: equal positions in the runs mean nearly equal columns
+    const int step_len = (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB > 0 ? (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB : SB;
     IdStage<L, 2> ids;
     if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
     for (int k = gq; k < KW; k += GW) {   // A rows of the bin -> LDS (behind the first id segment's request)
@@ -517,10 +497,10 @@ __global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
     int prev_e = -1;
     for (int jb = 0; jb < wave_total; jb += SB) {
       if (jb >= next_step_at) {   // wave-uniform
-        const int step = r * s.steps + jb / s.step_len;
+        const int step = r * s.steps + jb / step_len;
         pacer.signal_upto(step);
         pacer.wait_enter(step, step);
-        next_step_at = (jb / s.step_len + 1) * s.step_len;
+        next_step_at = (jb / step_len + 1) * step_len;
       }
       if (jb < total) {
         const int nb = (total - jb) < SB ? (total - jb) : SB;

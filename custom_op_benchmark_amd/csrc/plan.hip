@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void k_deal_fill(const int* __restrict__ strip
 }
 
 // ---- walk layout (common.h: Walk; kernels_walk.h) ------------------------------------------------------
-// The tape = slots [e0, e0 + etot) of the CSR in storage order; bin tb (one per WAVE and round) takes
-// [t0, t1) = e0 + [tb, tb + 1) * etot / bins.  Rows (plan segments) s0 .. s1 intersect it; a row
+// The tape = slots [e0, e0 + etot) of the CSR in storage order; bin tb (one per sharing set of lane groups
+// and round) takes [t0, t1) = bin_t[tb, tb + 1]: equal shares of the tape, except that a bin ends early
+// at the row boundary where it would take its (kmax + 1)-th row (the host cuts the tape, plan_get_walk:
+// graphs whose rows are much shorter than a share still fit, their bins are lighter and the others take
+// up the slack).  Rows (plan segments) s0 .. s1 intersect a bin; a row
 // [rs, re) of n slots contributes the piece [a, b) = [t0, t1) - rs clipped to [0, n), and INSIDE window
 // w -- the row's slots [lo_w, lo_w + n_w) there -- the slots lo_w + [a * n_w / n, b * n_w / n): the
 // pieces of a cut row tile each of its windows exactly (neighbouring bins compute the same quotient at
@@ -342,12 +345,11 @@ __device__ __forceinline__ i64 walk_upper(const i64* __restrict__ seg_eptr, i64 
   }
   return lo;
 }
-__device__ __forceinline__ WalkBin walk_bin(const i64* __restrict__ seg_eptr, i64 S, i64 tb, i64 bins, int kmax,
-                                            int* __restrict__ overflow) {
+__device__ __forceinline__ WalkBin walk_bin(const i64* __restrict__ seg_eptr, i64 S, i64 tb, const i64* __restrict__ bin_t,
+                                            int kmax, int* __restrict__ overflow) {
   WalkBin b;
-  const i64 e0 = seg_eptr[0], etot = seg_eptr[S] - e0;
-  b.t0 = e0 + (tb * etot) / bins;
-  b.t1 = e0 + ((tb + 1) * etot) / bins;
+  b.t0 = bin_t[tb];
+  b.t1 = bin_t[tb + 1];
   b.s0 = 0; b.nk = 0;
   if (b.t1 > b.t0) {
     const i64 s0 = walk_upper(seg_eptr, S, b.t0) - 1, s1 = walk_upper(seg_eptr, S, b.t1 - 1) - 1;
@@ -385,12 +387,12 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 
 // one wave per bin; bin_len[tb * GW + g] = slots of lane group g, rounded up to 4
 __global__ __launch_bounds__(256) void k_walk_count(const i64* __restrict__ seg_eptr, const int* __restrict__ rw,
-                                                    i64 S, int W, i64 bins, int GW, int kmax,
+                                                    i64 S, int W, i64 bins, const i64* __restrict__ bin_t, int GW, int kmax,
                                                     int* __restrict__ bin_len, int* __restrict__ overflow) {
   const i64 tb = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int k = threadIdx.x & 63;
   if (tb >= bins) return;
-  const WalkBin b = walk_bin(seg_eptr, S, tb, bins, kmax, overflow);
+  const WalkBin b = walk_bin(seg_eptr, S, tb, bin_t, kmax, overflow);
   int tot[4] = {0, 0, 0, 0};
   for (int w = 0; w < W; ++w) {
     int c0, c1;
@@ -404,14 +406,14 @@ __global__ __launch_bounds__(256) void k_walk_count(const i64* __restrict__ seg_
 __global__ __launch_bounds__(256) void k_walk_fill(const i64* __restrict__ seg_eptr, const int* __restrict__ rw,
                                                    const i64* __restrict__ seg_chunk, const i64* __restrict__ row,
                                                    const int32_t* __restrict__ idx32, const int32_t* __restrict__ eid32,
-                                                   i64 S, int W, i64 bins, int GW, int kmax,
+                                                   i64 S, int W, i64 bins, const i64* __restrict__ bin_t, int GW, int kmax,
                                                    const int* __restrict__ bin_pos, int* __restrict__ ids,
                                                    int* __restrict__ widx, int* __restrict__ bin_rows,
                                                    int* __restrict__ bin_total) {
   const i64 tb = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int k = threadIdx.x & 63;
   if (tb >= bins) return;
-  const WalkBin b = walk_bin(seg_eptr, S, tb, bins, kmax, nullptr);
+  const WalkBin b = walk_bin(seg_eptr, S, tb, bin_t, kmax, nullptr);
   if (k < kmax) {
     int rec = -1;
     if (k < b.nk) {
@@ -888,28 +890,58 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
                      (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, win_cols, (int*)rw.p);
   GO_LAUNCH_CHECK();
   GO_HIP(go_malloc(&ovf.p, sizeof(int), st));
-  // fewest rounds whose bins all hold <= kmax rows: start where the mean bin holds ~80 % of that
-  i64 rounds = ceil_div(S * 10, waves * kmax * 8);
+  // Cut the tape on the host (one pass over the row starts): bin b takes an equal share of what is left,
+  // ceil(remaining / bins left), but ends at the row boundary in front of its (kmax + 1)-th row.  Fewest
+  // rounds for which the bins take the whole tape.
+  std::vector<i64> h_eptr((size_t)(S + 1));
+  GO_HIP(hipMemcpyAsync(h_eptr.data(), seg_eptr.p, sizeof(i64) * (size_t)(S + 1), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+  const i64 e0 = h_eptr[0], e_end = h_eptr[(size_t)S];
+  std::vector<i64> h_t;
+  i64 rounds = ceil_div(S, waves * kmax);
   if (rounds < 1) rounds = 1;
-  i64 bins = 0;
+  i64 bins = 0, longest = 0;
   bool fit = false;
-  for (int attempt = 0; attempt < 8 && !fit; ++attempt, ++rounds) {
+  for (int attempt = 0; attempt < 12 && !fit; ++attempt, ++rounds) {
     bins = waves * rounds;
     if (bins * GW >= (1 << 24)) break;
-    go_free(len.p); len.p = nullptr;
-    GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(bins * GW + 1), st));
-    GO_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), st));
-    GO_HIP(hipMemsetAsync(len.p, 0, sizeof(int) * (size_t)(bins * GW + 1), st));
-    hipLaunchKernelGGL(k_walk_count, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
-                       (const int*)rw.p, S, W, bins, GW, kmax, (int*)len.p, (int*)ovf.p);
-    GO_LAUNCH_CHECK();
-    int h_ovf = 0;
-    GO_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    GO_HIP(hipStreamSynchronize(st));
-    fit = h_ovf == 0;
+    h_t.assign((size_t)(bins + 1), e_end);
+    i64 pos = e0, seg = 0;     // seg = the row that holds slot pos (or the next non-empty one)
+    longest = 0;
+    for (i64 b = 0; b < bins; ++b) {
+      h_t[(size_t)b] = pos;
+      if (pos >= e_end) continue;
+      const i64 target = ceil_div(e_end - pos, bins - b);
+      while (seg < S && h_eptr[(size_t)(seg + 1)] <= pos) ++seg;
+      i64 end = pos + target;
+      // the bin may touch rows seg .. seg + kmax - 1 (empty rows in between count: they hold a slot of the bin's table)
+      const i64 last_row = seg + kmax - 1 < S - 1 ? seg + kmax - 1 : S - 1;
+      if (h_eptr[(size_t)(last_row + 1)] < end) end = h_eptr[(size_t)(last_row + 1)];
+      if (end > e_end) end = e_end;
+      longest = end - pos > longest ? end - pos : longest;
+      pos = end;
+    }
+    h_t[(size_t)bins] = pos;
+    fit = pos >= e_end;
     if (fit) break;
   }
   if (!fit) return remember_unfit();
+  DevBuf bin_t;
+  GO_HIP(go_malloc(&bin_t.p, sizeof(i64) * (size_t)(bins + 1), st));
+  GO_HIP(hipMemcpyAsync(bin_t.p, h_t.data(), sizeof(i64) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
+  GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(bins * GW + 1), st));
+  GO_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), st));
+  GO_HIP(hipMemsetAsync(len.p, 0, sizeof(int) * (size_t)(bins * GW + 1), st));
+  hipLaunchKernelGGL(k_walk_count, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
+                     (const int*)rw.p, S, W, bins, (const i64*)bin_t.p, GW, kmax, (int*)len.p, (int*)ovf.p);
+  GO_LAUNCH_CHECK();
+  {
+    int h_ovf = 0;
+    GO_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    GO_HIP(hipStreamSynchronize(st));    // (also keeps h_t alive until the upload has been read)
+    if (h_ovf != 0) return remember_unfit();   // cannot happen: the host cut every bin at <= kmax rows
+  }
+  wk.longest_run = ceil_div(longest, GW) + W + 1;   // slots in the longest lane-group run (window shares round up)
   size_t tmp_bytes = 0;
   const i64 gbins = bins * GW;   // one run per lane group and round
   GO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)len.p, (int*)len.p, (int)(gbins + 1), st));
@@ -944,7 +976,7 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
     return fail(GRAPHOP_ERR_HIP);
   hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
                      (const int*)rw.p, (const i64*)p->seg_chunk, (const i64*)p->row, (const int32_t*)p->idx32,
-                     (const int32_t*)(p->info.eid_identity ? nullptr : p->eid32), S, W, bins, GW, kmax,
+                     (const int32_t*)(p->info.eid_identity ? nullptr : p->eid32), S, W, bins, (const i64*)bin_t.p, GW, kmax,
                      (const int*)wk.bin_pos, wk.ids, wk.widx, wk.bin_rows, wk.bin_cum);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
   vec->push_back(wk);
