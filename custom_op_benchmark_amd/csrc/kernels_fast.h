@@ -611,7 +611,7 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
   // vmcnt retires in issue order and a store is acknowledged later than an L2-hit load returns, so
   // every store instruction between two batches of row requests delays the rows behind it once;
   // kStoreBatch stores issued back to back share that delay.
-  constexpr int kStoreBatch = 4;
+  constexpr int kStoreBatch = NV == 1 ? 4 : 1;   // (wider rows have no registers to spare at 128 VGPRs)
   float held_res[kStoreBatch];
   int held_e[kStoreBatch];
 #pragma unroll

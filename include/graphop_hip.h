@@ -153,7 +153,13 @@ GRAPHOP_API int graphop_partition_csr_fill(const int64_t* indptr, const int64_t*
  * eid in [0,n_edges), indptr within range) and caches derived arrays.  Synchronises `stream`
  * once (setup path).  indices may be NULL (softmax / node_mul_edge only need row/indptr/eid).
  * n_index_bound <= 0 skips the range check of indices.  The arrays must stay alive and
- * unmodified while the plan is used. */
+ * unmodified while the plan is used.
+ * RANGE CHECKS NEED A PLAN: an op entry point compares the plan's largest row id / neighbour id with
+ * the operand sizes it is given (too few rows -> GRAPHOP_ERR_INVALID_ARGUMENT, no launch).  Called
+ * with plan = NULL (or a plan of other arrays) it has nothing to compare with and keeps the
+ * reference's behaviour: ids beyond an operand are out-of-bounds device accesses
+ * (graphop_kernel.cu does no shape validation at all).  Bindings that cannot vouch for the ids should
+ * always pass a plan; both bundled bindings do. */
 GRAPHOP_API int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t* eid,
                         const int64_t* indices, int64_t n_chunks, int64_t n_edges,
                         int64_t n_index_bound, void* stream, graphop_plan_t** plan_out);
@@ -165,7 +171,10 @@ GRAPHOP_API void graphop_plan_destroy(graphop_plan_t* plan);
  * SDDMM-type, SpMM-type and -- fused != 0 -- fused attention passes: fused = 1 for either side,
  * 2 when the plan is only ever the row-major side, 3 the column-major side).  After it no op call on
  * these shapes allocates or synchronises: required before capturing the ops into a HIP graph
- * (an op that would have to build one during capture fails with GRAPHOP_ERR_INVALID_ARGUMENT). */
+ * (an op that would have to build one during capture fails with GRAPHOP_ERR_INVALID_ARGUMENT).
+ * Also builds the walk layouts (csrc/kernels_walk.h) of the passes that take them.  Walk layouts are
+ * not part of the persistence interface below: a plan re-created by graphop_plan_import rebuilds them
+ * on first use (or in graphop_plan_prepare) from the imported arrays, a few milliseconds. */
 GRAPHOP_API int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, int64_t h,
                          int64_t d, int fused, void* stream);
 

@@ -47,14 +47,23 @@ def test_million_slot_row_and_column_vs_oracle(dev, drivers):
         assert {"k_sddmm_walk_f32", "k_spmm_walk_f32"} <= kernels, kernels
     elif drivers == "chunk":
         assert {"k_sddmm_f32", "k_spmm_f32"} <= kernels, kernels
-    # a 1.2 M-term fp32 sum: the reference's own accuracy on such a row is ~1e-3 relative (atomics in any order)
-    tol = dict(rtol=1e-3, atol=1e-4)
+    # The two hub rows are fp32 sums of 10^6 terms: any two summation orders (the oracle's serial loop, the
+    # reference's atomics in arrival order, pieces merged here) differ by ~sqrt(n) * 2^-24 * |terms| -- they get
+    # the tolerance north_star states (1e-3) on the scale of the row; every other row the suite's usual one.
+    hub = torch.tensor([4321, 98765])
+    rest = torch.ones(g.n_src, dtype=torch.bool); rest[hub] = False
+
+    def check_nodes(x, ref):
+        x = x.detach().cpu()
+        close(x[rest], ref[rest])
+        scale = float(ref[hub].abs().max())
+        torch.testing.assert_close(x[hub], ref[hub], rtol=1e-3, atol=1e-3 * max(scale, 1e-3))
     for k in ("s", "a"):
         close(got[k], want[k])
     for k in ("o", "dQ", "dK", "dV"):
-        close(got[k], want[k], **tol)
+        check_nodes(got[k], want[k])
     q, kk, v = (t.clone().requires_grad_(True) for t in args[:3])
     o2 = functions.fused_attention_step(gd, q, kk, v, args[3])
-    close(o2.detach(), want["o"], **tol)
+    check_nodes(o2, want["o"])
     for key, grad in (("dQ", q.grad), ("dK", kk.grad), ("dV", v.grad)):
-        close(grad, want[key], **tol)
+        check_nodes(grad, want[key])
