@@ -438,6 +438,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_t
     out->view.drift = t.walk_drift;
     out->view.sync = (t.walk_drift > 0 && !dry_run) ? plan_take_walk_sync(const_cast<graphop_plan*>(plan), wk) : nullptr;
     out->view.dbg = nullptr;
+    out->view.stream_weights = pi.eid_identity ? 1 : 0;
     out->blocks = (unsigned)blocks;
     out->lds_bytes = walk_lds_bytes<L, NV>();
     if (!dry_run && out->view.sync &&

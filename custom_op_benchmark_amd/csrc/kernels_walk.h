@@ -40,6 +40,7 @@ struct WalkView {
   int steps;             // pacing steps per round: a wave's step = position in its longest run / (that run's length / steps)
   int drift;             // a wave may start step s only once every wave of its XCD has left step s - drift
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
+  int stream_weights;    // 1: the per-slot weights are read in storage order (identity eid): nontemporal loads
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
 };
 
@@ -235,6 +236,9 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
     for (int g = 0; g < NG; ++g) chunk_base[g] = 0;
     long long t_space = 0;
+    // identity-eid slots read every weight line once, a run at a time: streamed past the caches; permuted slots
+    // share their lines with the neighbouring columns' lane groups of the same XCD: cached
+    auto ld_w = [&](int wi) { return s.stream_weights ? __builtin_nontemporal_load(wgt + wi) : wgt[wi]; };
     for (int r = 0; r < s.rounds; ++r) {
       int pos0[NG], total[NG], nchunk[NG], c[NG];
       int idW[NG], idA[NG], wiA[NG], wi0[NG];
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         if (ck * kFeedChunk < total[g]) {
           const int j = ck * kFeedChunk + h;
           const int jc = j < total[g] ? j : total[g] - 1;   // the tail of the last chunk repeats the last neighbour, weight 0
-          idw = s.ids[pos0[g] + jc];
-          if (j < total[g]) wi = s.widx[pos0[g] + jc];
+          idw = __builtin_nontemporal_load(s.ids + pos0[g] + jc);
+          if (j < total[g]) wi = __builtin_nontemporal_load(s.widx + pos0[g] + jc);
         }
       };
       int left = 0;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
       for (int g = 0; g < NG; ++g) load_pair(g, 1, idA[g], wiA[g]);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) wvW[g] = wi0[g] >= 0 ? wgt[wi0[g]] : 0.f;
+      for (int g = 0; g < NG; ++g) wvW[g] = wi0[g] >= 0 ? ld_w(wi0[g]) : 0.f;
       while (left > 0) {
         // one TURN: every lane group whose ring has room advances by a chunk.  All ring writes first (they
         // use what the previous turn requested: one wait per turn), then all weight requests, then all
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         for (int g = 0; g < NG; ++g) {
           if (!((adv >> g) & 1)) continue;
           idW[g] = idA[g];
-          wvW[g] = wiA[g] >= 0 ? wgt[wiA[g]] : 0.f;
+          wvW[g] = wiA[g] >= 0 ? ld_w(wiA[g]) : 0.f;
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
