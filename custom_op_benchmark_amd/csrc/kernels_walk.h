@@ -217,8 +217,9 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
   __shared__ int feed_ready[GPB], feed_done[GPB];
   int* ring_base = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4);   // [GPB][2][RING]: ids, weights
   if (threadIdx.x < GPB) { feed_ready[threadIdx.x] = 0; feed_done[threadIdx.x] = 0; }
+  __syncthreads();                   // the zeroed hand-over words, whether or not the launch is paced
   const long long t_start = __builtin_amdgcn_s_memtime();
-  WalkPacer pacer(s, pace_words, kWalkWorkers / kWave);    // (its barrier also publishes the zeroed hand-over words)
+  WalkPacer pacer(s, pace_words, kWalkWorkers / kWave);
 
   if (threadIdx.x >= kWalkWorkers) {
     // ---------------- feeder wave ----------------
