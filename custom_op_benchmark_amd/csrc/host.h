@@ -89,8 +89,8 @@ struct Tuning {
     walk = env_int("GRAPHOP_WALK", 6);   // SDDMM-type passes: the window-owner drivers measure 1.55-1.6 ms against 1.63-1.73
     walk_window_kb = env_int("GRAPHOP_WALK_WINDOW_KB", 4096);
     walk_window_kb_col = env_int("GRAPHOP_WALK_WINDOW_KB_COL", 2048);
-    walk_drift = env_int("GRAPHOP_WALK_DRIFT", 2);
-    walk_steps = env_int("GRAPHOP_WALK_STEPS", 1);
+    walk_drift = env_int("GRAPHOP_WALK_DRIFT", 3);
+    walk_steps = env_int("GRAPHOP_WALK_STEPS", 2);
     walk_min_bin = env_int("GRAPHOP_WALK_MIN_BIN", 1024);
     walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);

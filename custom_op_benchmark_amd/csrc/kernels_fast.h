@@ -613,7 +613,8 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
   // kStoreBatch stores issued back to back share that delay.  Nontemporal: 1.50 -> 1.46 ms per pass on the Reddit
   // shape once the stores are batched (plain stores were the faster form while there was one per batch; write-through
   // agent-scope stores measure 1.73).
-  constexpr int kStoreBatch = NV == 1 ? 4 : 1;   // (wider rows have no registers to spare at 128 VGPRs)
+  // (measured at 256-B rows; 1-KB rows got slower with it, 8.1 -> 10.0 ms per pass at d = 256, and keep one plain store per batch)
+  constexpr int kStoreBatch = (NV == 1 && L == 16) ? 4 : 1;
   float held_res[kStoreBatch];
   int held_e[kStoreBatch];
 #pragma unroll
@@ -622,7 +623,10 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
   auto flush_results = [&]() {
 #pragma unroll
     for (int q = 0; q < kStoreBatch; ++q) {
-      if (held_e[q] >= 0) __builtin_nontemporal_store(held_res[q], y + held_e[q]);
+      if (held_e[q] >= 0) {
+        if constexpr (kStoreBatch > 1) __builtin_nontemporal_store(held_res[q], y + held_e[q]);
+        else y[held_e[q]] = held_res[q];
+      }
       held_e[q] = -1;
     }
     n_held = 0;

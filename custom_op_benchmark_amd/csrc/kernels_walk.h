@@ -3,27 +3,24 @@
 // The window-owner drivers (kernels_fast.h) let every XCD own column windows; a row's partial sum
 // then leaves the chip once per (row, window) -- memory-side float atomics, 1-1.4 GB per pass on
 // the Reddit shape -- and the A rows of an SDDMM-type pass are re-read per (row, window).  Here the
-// ownership is turned around: a WAVE owns a BIN of rows for a whole round (plan.hip cuts the CSR,
-// read as one tape of slots, into waves x rounds bins of equal length) and keeps them in LDS --
-// partial sums of an SpMM-type pass, A rows of an SDDMM-type pass -- while it walks ALL column
-// windows, window 0 first.  All waves of the chip therefore gather from the same part of the table
-// at about the same time, which keeps that part in every XCD's L2; a per-XCD soft pacer
-// (WalkPacer) bounds how far a wave may run ahead.  Nothing is flushed per window: a row is written
-// once per round (plain stores; atomics only for the <= 2 rows a bin shares with its neighbours).
+// ownership is turned around: a lane group's LDS holds a BIN of rows for a whole round (plan.hip cuts
+// the CSR, read as one tape of slots, into bins of equal length) -- partial sums of an SpMM-type pass,
+// A rows of an SDDMM-type pass -- while ALL column windows are walked, window 0 first.  All waves of
+// the chip therefore gather from the same part of the table at about the same time, which keeps
+// that part in every XCD's L2; a per-XCD soft pacer (WalkPacer) bounds how far a CU may run ahead.
+// Nothing is flushed per window: a row is written once per round (plain stores; atomics only for
+// the <= 2 rows a bin shares with its neighbours).
 //
-// Inside every window the bin's slots are dealt to the wave's lane groups in equal contiguous
-// shares, and a lane group's shares of all windows are one contiguous run of (row-in-bin |
-// neighbour id, edge id) pairs streamed through the group's LDS ring (IdStage, two streams): a
-// strip is ONE flat list of full 16-slot batches for the whole round -- no per-window round-up, no
-// dealing -- and the groups of a wave, which run in lock step, are always in the same window.
-// Where a bin stands in the table after a given share of its slots varies from bin to bin like
-// 1 / sqrt(slots per bin) (which windows a row's neighbours fall into is random): bins per wave
-// rather than per lane group halve that spread, which is what the L2 has to hold.
-// SH = lane groups that share one bin (template parameter of the kernels, `GW` of the layout):
-// SH = 1 is a bin per lane group (its rows are its own: partial sums are folded into LDS with a
-// plain, deferred read-modify-write); SH = lane groups of a wave is a bin per wave (measured on the
-// SDDMM-type passes, which only read the rows: 1.76 -> 1.66 ms on the Reddit shape; the SpMM-type
-// passes would have to order the updates of rows cut between two groups: 1.78 -> 2.03 ms).
+// A bin's slots are stored window-major as one contiguous run of (row-in-bin | neighbour id, edge
+// id) pairs per lane group: a strip is ONE flat list of full 16-slot batches for the whole round --
+// no per-window round-up, no dealing.  Where a bin stands in the table after a given share of its
+// slots varies from bin to bin like 1 / sqrt(slots per bin) (which windows a row's neighbours fall
+// into is random); that spread is what the L2 has to hold.
+// `GW` of the layout = lane groups that share one bin: 1 for the SpMM-type kernel (the rows are the lane
+// group's own: partial sums are folded into LDS with a plain, deferred read-modify-write); the lane
+// groups of a wave for the SDDMM-type kernel, which only reads the rows (half the spread: 1.76 ->
+// 1.66 ms on the Reddit shape; SpMM-type passes would have to order the updates of rows cut between
+// two groups: 1.78 -> 2.03 ms).
 #pragma once
 #include "kernels_fast.h"
 
@@ -85,6 +82,24 @@ struct WalkPacer {
     done_next = upto;
     if (active && (threadIdx.x & (kWave - 1)) == 0) {
       __hip_atomic_store(lds + (threadIdx.x >> 6), upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int m = upto;
+      for (int w = 0; w < n_waves; ++w) {
+        const int o = __hip_atomic_load(lds + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        m = o < m ? o : m;
+      }
+      const int from = __hip_atomic_fetch_max(lds + 8, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int st = from; st < m; ++st) {
+        int* c = ctr + (i64)st * 2 * kSyncStride;
+        const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 >= n) __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // progress slot `slot` (a quad of the ticketed walk kernel; n_waves = number of slots) has finished all steps < upto
+  __device__ __forceinline__ void signal_slot(int slot, int upto) {
+    if (active && (threadIdx.x & (kWave - 1)) == 0) {
+      __hip_atomic_store(lds + slot, upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       int m = upto;
       for (int w = 0; w < n_waves; ++w) {
         const int o = __hip_atomic_load(lds + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -216,10 +231,15 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
   __shared__ int pace_words[16];
   __shared__ int feed_ready[GPB], feed_done[GPB];
   int* ring_base = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4);   // [GPB][2][RING]: ids, weights
-  if (threadIdx.x < GPB) { feed_ready[threadIdx.x] = 0; feed_done[threadIdx.x] = 0; }
+  constexpr int GW = kWave / L, NQ = GPB / GW;      // lane groups per wave; quads (see the worker waves) per workgroup
+  static_assert(NQ <= 8, "pacer progress words");
+  __shared__ int tk_next, quad_done[NQ], quad_len[NQ], bin_total[GPB], bin_seg[GPB];
+  if (threadIdx.x < GPB) { feed_ready[threadIdx.x] = 0; feed_done[threadIdx.x] = 0; bin_total[threadIdx.x] = 0; bin_seg[threadIdx.x] = 0; }
+  if (threadIdx.x < NQ) { quad_done[threadIdx.x] = 0; quad_len[threadIdx.x] = SB; }
+  if (threadIdx.x == 0) tk_next = 0;
   __syncthreads();                   // the zeroed hand-over words, whether or not the launch is paced
   const long long t_start = __builtin_amdgcn_s_memtime();
-  WalkPacer pacer(s, pace_words, kWalkWorkers / kWave);
+  WalkPacer pacer(s, pace_words, NQ);               // progress is kept per quad (below), not per wave
 
   if (threadIdx.x >= kWalkWorkers) {
     // ---------------- feeder wave ----------------
@@ -325,31 +345,70 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
   }
 
   // ---------------- worker waves ----------------
+  // The bins (lane groups' row sets, LDS-resident) belong to the WORKGROUP, not to a wave: a QUAD = the GW
+  // bins one wave's lane groups process in lock step; (pacing step, quad) units are handed out through a
+  // ticket counter in LDS, step-major.  A wave that is ahead simply takes the next unit -- of whichever
+  // quad -- so the waves of a CU finish a step together however unevenly the memory system served them,
+  // and the XCD pacer has to bound the spread of 32 CUs instead of 256 waves.  A unit starts when its
+  // quad's previous step is finished (quad_done); between two units of a bin its state is in LDS: the
+  // partial sums, the position in the run, the feeder ring.
   const int l = threadIdx.x % L;
-  const int g_in_blk = threadIdx.x / L;
-  float4* accs = lds + (i64)g_in_blk * kWalkK * F4;   // [kWalkK][NV][L]
-  const int* ring = ring_base + g_in_blk * 2 * RING;
-  int seg_base = 0;                                   // segments of earlier rounds
-  for (int r = 0; r < s.rounds; ++r) {
-    const i64 tb = walk_bin_index_of<GPB>(s, r, g_in_blk);
-    const int total = s.bin_cum[tb];
-    const int my_row = l < kWalkK ? s.bin_rows[tb * kWalkK + l] : -1;
-    int next_step_at = 0;
+  const int gq = (threadIdx.x / L) % GW;              // lane group inside the wave
+  const int n_steps = s.rounds * s.steps;
+  for (;;) {
+    int t = 0;
+    if ((threadIdx.x & (kWave - 1)) == 0)
+      t = __hip_atomic_fetch_add(&tk_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int gstep = t / NQ, q = t % NQ;             // step-major: the quads of a step are taken before the next step's
+    if (gstep >= n_steps) break;
+    const int r = gstep / s.steps, sidx = gstep - r * s.steps;
+    {
+      int it = 0;
+      const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
+      while (lds_ld(quad_done + q) < gstep) {         // the quad's previous step is still being worked on
+        __builtin_amdgcn_s_sleep(1);
+        if (++it > (1 << 24)) break;                  // (never observed; bounds the spin)
+      }
+      if (s.dbg) pacer.t_feed += __builtin_amdgcn_s_memtime() - t0;
+    }
+    pacer.wait_enter(gstep, gstep);
+    const int bin = q * GW + gq;
+    float4* accs = lds + (i64)bin * kWalkK * F4;      // [kWalkK][NV][L]
+    const int* ring = ring_base + bin * 2 * RING;
+    const i64 tb = walk_bin_index_of<GPB>(s, r, bin);
+    int total, step_len;
+    if (sidx == 0) {                                  // the bin's round starts with this unit
+      total = s.bin_cum[tb];
 #pragma unroll
-    for (int k = 0; k < kWalkK; ++k)
+      for (int k = 0; k < kWalkK; ++k)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int wave_total = wave_max_int<L>(total);
-    // pacing steps = equal shares of this wave's longest run: equal positions in the runs mean nearly equal columns
-    const int step_len = (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB > 0 ? (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB : SB;
+        for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int quad_total = wave_max_int<L>(total);
+      // pacing steps = equal shares of the quad's longest run: equal positions in the runs mean nearly equal columns
+      step_len = (((quad_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB;
+      step_len = step_len > 0 ? step_len : SB;
+      if (l == 0) bin_total[bin] = total;
+      if ((threadIdx.x & (kWave - 1)) == 0) quad_len[q] = step_len;
+    } else {
+      total = bin_total[bin];
+      step_len = quad_len[q];
+    }
+    const int seg_base = bin_seg[bin];                // chunks of earlier rounds
+    const int j0 = sidx * step_len;
+    int j1 = j0 + step_len;
+    {
+      const int quad_total = wave_max_int<L>(total);
+      j1 = j1 < quad_total ? j1 : quad_total;
+    }
     float4 acc[NV], pend_acc[NV], pend_rd[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     int k_cur = -1, pend_k = -1;
     // Row change: the partial sum of the row just left is folded into its LDS row by a DEFERRED
     // read-modify-write -- the LDS row is requested now, added and written back at the NEXT row
-    // change -- so no LDS round trip sits between two slots' multiply-adds.  The rows are this lane
-    // group's own and a row's slots of one window are contiguous, so nobody touches the row in between.
+    // change -- so no LDS round trip sits between two slots' multiply-adds.  The bin is this lane
+    // group's for the whole unit and a row's slots of one window are contiguous, so nobody touches the row in between.
     auto finish_pending = [&]() {
       if (pend_k >= 0) {
 #pragma unroll
@@ -397,14 +456,12 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     auto stage = [&](int jb, Meta& m, unsigned& off) {
       if ((jb % kFeedChunk) == 0) {                   // entering a chunk: earlier ones are read, this one must be there
         const int gs = seg_base + jb / kFeedChunk;
-        lds_st(feed_done + g_in_blk, gs);
+        lds_st(feed_done + bin, gs);
         int it = 0;
-        const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
-        while (lds_ld(feed_ready + g_in_blk) <= gs) {
+        while (lds_ld(feed_ready + bin) <= gs) {
           __builtin_amdgcn_s_sleep(1);
           if (++it > (1 << 22)) break;                // (never observed; bounds the spin)
         }
-        if (s.dbg) pacer.t_feed += __builtin_amdgcn_s_memtime() - t0;
       }
       const int at = (seg_base * kFeedChunk + jb + l) % RING;
       const int idw = ring[at];
@@ -412,16 +469,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
       m.w = __int_as_float(ring[RING + at]);
     };
-    if (total > 0) stage(0, mc, off_c);
-    for (int jb = 0; jb < wave_total; jb += SB) {
-      // pacing by progress: all bins hold the same number of slots (+- W), so equal positions in their
-      // runs mean nearly equal columns
-      if (jb >= next_step_at) {   // wave-uniform
-        const int step = r * s.steps + jb / step_len;
-        pacer.signal_upto(step);
-        pacer.wait_enter(step, step);
-        next_step_at = (jb / step_len + 1) * step_len;
-      }
+    if (j0 < total && j0 < j1) stage(j0, mc, off_c);
+    for (int jb = j0; jb < j1; jb += SB) {
       if (jb < total) {
         static_for<SB>([&](auto uc) {
           constexpr int u = decltype(uc)::value;
@@ -429,32 +478,38 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
           for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
         });
-        if (jb + SB < total) stage(jb + SB, mn, off_n);
+        if (jb + SB < total && jb + SB < j1) stage(jb + SB, mn, off_n);
         consume(x, mc);
         mc = mn; off_c = off_n;
       }
     }
-    seg_base += (total + kFeedChunk - 1) / kFeedChunk;
-    lds_st(feed_done + g_in_blk, seg_base);
     row_change(-1);      // the last row becomes the pending one ...
-    finish_pending();    // ... and is folded in
-    pacer.signal_upto((r + 1) * s.steps);
-    // the bin's rows leave the chip once: plain stores for rows that are wholly inside the bin, float
-    // atomics for the (at most two) rows it shares with its neighbours
-    for (int k = 0; k < kWalkK; ++k) {
-      const int rec = __shfl(my_row, k, L);
-      if (rec == -1) continue;   // group-uniform
-      const i64 row = rec & 0x7fffffff;
-      float4 a[NV];
+    finish_pending();    // ... and is folded in: the bin's state is in LDS again
+    if (sidx == s.steps - 1) {
+      // the bin's round is over: its rows leave the chip once -- plain stores for rows that are wholly inside
+      // the bin, float atomics for the (at most two) rows it shares with its neighbours
+      const int n_ch = (total + kFeedChunk - 1) / kFeedChunk;
+      if (l == 0) bin_seg[bin] = seg_base + n_ch;
+      lds_st(feed_done + bin, seg_base + n_ch);
+      const int my_row = l < kWalkK ? s.bin_rows[tb * kWalkK + l] : -1;
+      for (int k = 0; k < kWalkK; ++k) {
+        const int rec = __shfl(my_row, k, L);
+        if (rec == -1) continue;   // group-uniform
+        const i64 row = rec & 0x7fffffff;
+        float4 a[NV];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) a[v] = accs[(k * NV + v) * L + l];
-      if (rec < 0) {
-        atomic_flush_dense<L, NV>(out, row, a, l);
-      } else {
+        for (int v = 0; v < NV; ++v) a[v] = accs[(k * NV + v) * L + l];
+        if (rec < 0) {
+          atomic_flush_dense<L, NV>(out, row, a, l);
+        } else {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[row * F4 + v * L + l] = a[v];
+          for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[row * F4 + v * L + l] = a[v];
+        }
       }
     }
+    // this quad has finished the step (LDS operations of a wave execute in order: the state above is visible first)
+    if ((threadIdx.x & (kWave - 1)) == 0) lds_st(quad_done + q, gstep + 1);
+    pacer.signal_slot(q, gstep + 1);
   }
   pacer.report(s.dbg, t_start);
 }

@@ -16,7 +16,7 @@ DEFAULTS = dict(sweep=1, sweep_mode=1, window_kb=4096, mall_window_kb=32768, max
                 sweep_min_kb=4608, sweep_bpc=3, sweep_k=0, vrow_t=0, sweep_drift=2, sweep_min_granule=4,
                 sweep_prefetch=0, transpose_scalars=0, sweep_w=0, spmm_window_scale=2,
                 attn_fused=1, attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1, staged_ids=7,
-                walk=6, walk_window_kb=4096, walk_window_kb_col=2048, walk_drift=2, walk_min_bin=1024, walk_blocks=0, walk_steps=1)
+                walk=6, walk_window_kb=4096, walk_window_kb_col=2048, walk_drift=3, walk_min_bin=1024, walk_blocks=0, walk_steps=2)
 
 
 def main():
