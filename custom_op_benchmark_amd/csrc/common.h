@@ -106,7 +106,7 @@ struct Sweep {
 };
 // Walk layout of one plan (kernels_walk.h): the slots of the CSR, read as one tape, are cut into
 // waves * rounds BINS of equal length; bin (round r, wave q) is what wave q of the resident grid
-// works on in round r.  A bin holds at most kWalkK * GW rows (whole rows, plus the pieces of the rows
+// works on in round r.  A bin holds at most K * GW rows (whole rows, plus the pieces of the rows
 // its two ends cut; a piece takes its share of the row's slots inside EVERY column window).  Inside
 // every window the bin's slots are dealt to the wave's GW lane groups in equal contiguous shares; a
 // lane group's shares of windows 0, 1, ... are stored as ONE contiguous run: per slot the neighbour
@@ -119,13 +119,14 @@ struct Walk {
   i64 win_cols = 0;
   int groups = 0;         // lane groups of the resident grid the tape was cut for
   int GW = 0;             // lane groups per wave
+  int K = 0;              // rows per lane group (<= kWalkK; fewer when the kernel's LDS also holds per-head weight rings)
   int rounds = 0;
   int xcd_slots = 0;      // 8 (groups % 8 == 0: every XCD slot owns a contiguous share of each round's tape) or 1
   long long n_slots = 0;  // ints in ids / widx (bins padded to 4, slack for whole-segment fetches)
   int* ids = nullptr;     // [(k << kWalkKShift) | neighbour id]
   int* widx = nullptr;    // edge id per slot
   int* bin_pos = nullptr; // [bins * GW + 1] first slot of every lane group's run
-  int* bin_rows = nullptr;// [bins * kWalkK * GW] row id | (shared << 31), -1 = unused
+  int* bin_rows = nullptr;// [bins * K * GW] row id | (shared << 31), -1 = unused
   int* bin_cum = nullptr; // [bins * GW] slots in every lane group's run
   int* sync = nullptr;    // kWalkSyncRing sets of pacer counters of the walk kernels (a set is zeroed before the launch that takes it)
   long long sync_ints = 0;  // ints per set
@@ -134,7 +135,7 @@ struct Walk {
   long long longest_run = 0;  // slots in the longest lane-group run (pacing steps are cut from it)
 };
 constexpr int kWalkSyncRing = 4;
-constexpr int kWalkK = 15;        // rows per lane group: 15 x 256 B + a 1 KB ring, x 32 lane groups = 152 KB of a CU's 160 KB LDS
+constexpr int kWalkK = 15;        // most rows per lane group: 15 x 256 B + a 1 KB ring, x 32 lane groups = 152 KB of a CU's 160 KB LDS
 constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)

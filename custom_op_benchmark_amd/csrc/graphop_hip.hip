@@ -125,7 +125,7 @@ int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Swe
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
-int plan_get_walk(graphop_plan*, int, i64, int, int, int, hipStream_t, const Walk**);
+int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**);
 int* plan_take_walk_sync(graphop_plan*, const Walk*);
 
 Tuning& tuning_mut() {
@@ -339,6 +339,8 @@ inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
   return (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
 }
 
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 // ---- walk drivers (kernels_walk.h) -----------------------------------------------------------------
 struct WalkLaunch {
   WalkView view;
@@ -392,8 +394,9 @@ struct WalkDebug {
 // table of n_table_rows rows, and fetch / build the layout.  1 = use it, 0 = no, < 0 = error (negated).
 // `SH` = lane groups per bin of the layout (kernels_walk.h): 1 for the SpMM-type kernel, the lane groups of a
 // wave for the SDDMM-type kernel.
+// `K` = rows per lane group the kernel's LDS holds.
 template <int L, int NV>
-int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_threads, int wgs_per_cu, hipStream_t st,
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int worker_threads, int wgs_per_cu, hipStream_t st,
                 WalkLaunch* out, bool dry_run = false) {
   if constexpr (NV != 1 || L < 16) {
     return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
@@ -419,15 +422,17 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int worker_t
     if (blocks >= 8) blocks -= blocks % 8; else slots = 1;
     const i64 groups = blocks * GPB;
     if (pi.n_edges < groups * (i64)t.walk_min_bin) return 0;
-    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc && spmm_walk_lds_bytes<L, NV>() + 1024 <= 160 * 1024, "LDS per CU");
+    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc, "LDS per CU");
+    if (K < 1 || K > kWalkK) return 0;
     const Walk* wk = nullptr;
-    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, SH,
+    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, SH, K,
                                  slots, st, &wk);
     if (rc != GRAPHOP_OK) return -rc;
     if (!wk) return 0;
     out->view.ids = wk->ids; out->view.widx = wk->widx; out->view.bin_pos = wk->bin_pos;
     out->view.bin_rows = wk->bin_rows; out->view.bin_cum = wk->bin_cum;
     out->view.W = wk->W; out->view.groups = wk->groups; out->view.rounds = wk->rounds;
+    out->view.K = wk->K;
     out->view.xcd_slots = slots;
     {
       i64 steps = (i64)wk->W * (t.walk_steps > 0 ? t.walk_steps : 1);
@@ -456,7 +461,7 @@ int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   } else {
     if (!(tuning().walk & 1) || h != 1 || !plan) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kFastBlock, kWalkBpc, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kWalkK, kFastBlock, kWalkBpc, st, &wl);
     if (use != 1) return use;
     static const bool attr = hipFuncSetAttribute((const void*)k_sddmm_walk_f32<L, NV>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
@@ -470,35 +475,58 @@ int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, 
   }
 }
 
+// Rows per lane group of the SpMM-type walk kernel for `h` heads (0 = the pass does not take the walk): what the
+// LDS holds next to the per-head weight rings, at least 8 (fewer rows = more rounds = more table streams).
+template <int L, int NV>
+inline int spmm_walk_k(i64 h) {
+  if (h != 1 && h != 2 && h != 4 && h != 8) return 0;
+  if (h > 1 && (NV != 1 || (4 * L) % h != 0 || (4 * L / h) % 4 != 0)) return 0;   // a lane's float4 lies inside one head
+  const int k = spmm_walk_rows<L, NV>((int)h);
+  return k >= 8 ? k : 0;
+}
+
 template <int L, int NV>
 int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w, const void* X,
-                  void* out, i64 h, hipStream_t st) {
+                  void* out, i64 h, int d4, hipStream_t st) {
   if constexpr (NV != 1 || L < 16) {
     return 0;
   } else {
-    if (h != 1 || !plan) return 0;
+    if (!plan) return 0;
     if (!(tuning().walk & (plan->info.eid_identity ? 2 : 4))) return 0;
+    const int K = spmm_walk_k<L, NV>(h);
+    if (K == 0 || (h > 1 && !aligned16(w))) return 0;
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, kWalkWorkers, 1, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, K, kWalkWorkers, 1, st, &wl);
     if (use != 1) return use;
-    static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
-    (void)attr;
-    static_assert(spmm_walk_lds_bytes<L, NV>() + 1024 <= 160 * 1024, "one walk workgroup per CU");
     WalkDebug dbg;
     dbg.arm(&wl, tag, st, kWalkWorkers / kWave);
     ProfScope prof(tag, st, "k_spmm_walk_f32");
-    constexpr size_t lds_bytes = spmm_walk_lds_bytes<L, NV>();
-    if (tuning().walk_debug) {
-      int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spmm_walk_f32<L, NV>, kWalkThreads, lds_bytes);
-      hipFuncAttributes fa;
-      (void)hipFuncGetAttributes(&fa, (const void*)k_spmm_walk_f32<L, NV>);
-      fprintf(stderr, "[walk] occupancy API: %d workgroups of %d threads per CU (dynamic LDS %zu, static %zu, regs %d)\n", nb, kWalkThreads,
-              lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs);
+    auto go = [&](auto hc) {
+      constexpr int HV = decltype(hc)::value;
+      if constexpr (spmm_walk_rows<L, NV>(HV) < 8) return;    // (spmm_walk_k said no: never instantiated)
+      else {
+      static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV, HV>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+      (void)attr;
+      const size_t lds_bytes = spmm_walk_lds_bytes<L, NV>(K, HV);
+      if (tuning().walk_debug) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spmm_walk_f32<L, NV, HV>, kWalkThreads, lds_bytes);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, (const void*)k_spmm_walk_f32<L, NV, HV>);
+        fprintf(stderr, "[walk] occupancy API: %d workgroups of %d threads per CU (dynamic LDS %zu, static %zu, regs %d, K %d)\n", nb,
+                kWalkThreads, lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs, K);
+      }
+      hipLaunchKernelGGL((k_spmm_walk_f32<L, NV, HV>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view,
+                         (const float*)w, (const float*)X, (float*)out, d4);
+      }
+    };
+    switch ((int)h) {
+      case 1: go(std::integral_constant<int, 1>{}); break;
+      case 2: go(std::integral_constant<int, 2>{}); break;
+      case 4: go(std::integral_constant<int, 4>{}); break;
+      default: go(std::integral_constant<int, 8>{}); break;
     }
-    hipLaunchKernelGGL((k_spmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view,
-                       (const float*)w, (const float*)X, (float*)out);
     return 1;
   }
 }
@@ -639,7 +667,6 @@ inline BlockView block_view(const graphop_plan* plan) {
   bv.idx32 = plan->idx32; bv.eid32 = plan->eid32; bv.nb = (int)plan->info.n_dense_blocks;
   return bv;
 }
-inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Returns 1 when the block-dense SDDMM ran, 0 when it does not apply.
 inline int try_sddmm_block(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows,
@@ -759,7 +786,7 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
     const int F = (int)(h * d), d4 = (int)(d / 4);
     {
       int use = 0;
-      GO_DISPATCH_LNV(F, { use = try_spmm_walk<L, NV>(tag, plan, n_src_rows, w, X, out, h, st); });
+      GO_DISPATCH_LNV(F, { use = try_spmm_walk<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
       GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, other, n_other_cols, st); });
@@ -1144,12 +1171,12 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
     if constexpr (NV == 1 && L >= 16) {
       WalkLaunch wl;
       const int bit = plan->info.eid_identity ? 2 : 4;
-      if (rc >= 0 && h == 1 && (tuning().walk & bit)) {
-        const int r2 = choose_walk<L, NV>(plan, n_table_rows, 1, kWalkWorkers, 1, st, &wl, /*dry_run=*/true);
+      if (rc >= 0 && spmm_walk_k<L, NV>(h) > 0 && (tuning().walk & bit)) {
+        const int r2 = choose_walk<L, NV>(plan, n_table_rows, 1, spmm_walk_k<L, NV>(h), kWalkWorkers, 1, st, &wl, /*dry_run=*/true);
         if (r2 < 0) rc = r2;
       }
       if (rc >= 0 && h == 1 && (tuning().walk & 1)) {
-        const int r2 = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kFastBlock, kWalkBpc, st, &wl, /*dry_run=*/true);
+        const int r2 = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kWalkK, kFastBlock, kWalkBpc, st, &wl, /*dry_run=*/true);
         if (r2 < 0) rc = r2;
       }
     }

@@ -34,6 +34,7 @@ struct WalkView {
   const int* bin_cum;    // [bins * GW] slots in every lane group's run
   int* sync;             // pacer counters, zero at launch (nullptr = free-running)
   int W, groups, rounds;
+  int K;                 // rows per lane group of the layout (Walk::K; LDS rows of a bin)
   int steps;             // pacing steps per round: a wave's step = position in its longest run / (that run's length / steps)
   int drift;             // a wave may start step s only once every wave of its XCD has left step s - drift
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
@@ -201,10 +202,20 @@ constexpr int kWalkWorkers = 512;  // worker threads
 constexpr int kFeeders = 4;        // feeder waves, each serving GPB / kFeeders lane groups
 constexpr int kWalkThreads = kWalkWorkers + kFeeders * kWave;
 
+// LDS of the SpMM-type walk kernel: per lane group K rows + a ring of (id, HV per-head weights) per slot
 template <int L, int NV>
-__host__ __device__ constexpr size_t spmm_walk_lds_bytes() {
-  return (size_t)(kWalkWorkers / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)kFeedChunk * kFeedRing * 8);
+__host__ __device__ constexpr size_t spmm_walk_lds_bytes(int K, int HV) {
+  return (size_t)(kWalkWorkers / L) * ((size_t)K * L * NV * 16 + (size_t)kFeedChunk * kFeedRing * 4 * (1 + HV));
 }
+// most rows per lane group that fit next to the rings (one workgroup per CU, 2 KB left to the static words)
+template <int L, int NV>
+__host__ __device__ constexpr int spmm_walk_rows(int HV) {
+  const long long per_group = (160LL * 1024 - 2048) / (kWalkWorkers / L) - (long long)kFeedChunk * kFeedRing * 4 * (1 + HV);
+  const long long k = per_group / ((long long)L * NV * 16);
+  return (int)(k > kWalkK ? kWalkK : (k < 0 ? 0 : k));
+}
+typedef float walk_f4 __attribute__((ext_vector_type(4)));
+typedef float walk_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lds_ld(const int* p) {
   const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -217,20 +228,26 @@ __device__ __forceinline__ void lds_st(int* p, int v) {
   asm volatile("" ::: "memory");
 }
 
-// out[row] = sum over the row's slots of w[edge] * X[neighbour]   (graphop_kernel.cu:100-112, :118-130, :151-163)
-// Bins per lane group (SH = 1): the LDS rows are the group's own.
-template <int L, int NV>
+// out[row, f] = sum over the row's slots of w[edge, head(f)] * X[neighbour, f]   (graphop_kernel.cu:100-112, :118-130, :151-163)
+// Bins per lane group (SH = 1): the LDS rows are the group's own.  HV = heads (a row is HV x d floats, d4 = d / 4
+// float4s per head; w holds HV scalars per edge): the feeder stages all HV weights of a slot, a worker
+// lane reads its head's.
+template <int L, int NV, int HV>
 __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second bound: waves per SIMD)
-    WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out) {
+    WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out, int d4) {
   extern __shared__ float4 lds[];
   constexpr int GPB = kWalkWorkers / L;
   constexpr i64 F4 = (i64)L * NV;
   constexpr int SB = StripCfg<L, NV>::SB;
   constexpr int RING = kFeedChunk * kFeedRing;
+  constexpr int RSTRIDE = RING * (1 + HV);           // ints per lane group's ring: ids, then HV weights per slot
+  constexpr bool H1 = HV == 1;
   static_assert(L >= 16 && kWalkK <= L && SB == 16 && kFeedChunk % SB == 0, "lane k of a group holds the bin's k-th row");
+  static_assert(HV == 1 || HV == 2 || HV == 4 || HV == 8, "heads");
+  const int K = s.K;
   __shared__ int pace_words[16];
   __shared__ int feed_ready[GPB], feed_done[GPB];
-  int* ring_base = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4);   // [GPB][2][RING]: ids, weights
+  int* ring_base = reinterpret_cast<int*>(lds + (i64)GPB * K * F4);   // [GPB][RSTRIDE]
   constexpr int GW = kWave / L, NQ = GPB / GW;      // lane groups per wave; quads (see the worker waves) per workgroup
   static_assert(NQ <= 8, "pacer progress words");
   __shared__ int tk_next, quad_done[NQ], quad_len[NQ], bin_total[GPB], bin_seg[GPB];
@@ -259,11 +276,29 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     long long t_space = 0;
     // identity-eid slots read every weight line once, a run at a time: streamed past the caches; permuted slots
     // share their lines with the neighbouring columns' lane groups of the same XCD: cached
-    auto ld_w = [&](int wi) { return s.stream_weights ? __builtin_nontemporal_load(wgt + wi) : wgt[wi]; };
+    auto ld_w = [&](int wi, float (&o)[HV]) {
+      if (wi < 0) {
+#pragma unroll
+        for (int i = 0; i < HV; ++i) o[i] = 0.f;
+      } else if constexpr (HV == 1) {
+        o[0] = s.stream_weights ? __builtin_nontemporal_load(wgt + wi) : wgt[wi];
+      } else if constexpr (HV == 2) {
+        const walk_f2* q = reinterpret_cast<const walk_f2*>(wgt) + wi;
+        const walk_f2 t = s.stream_weights ? __builtin_nontemporal_load(q) : *q;
+        o[0] = t.x; o[1] = t.y;
+      } else {
+#pragma unroll
+        for (int i = 0; i < HV / 4; ++i) {
+          const walk_f4* q = reinterpret_cast<const walk_f4*>(wgt) + (i64)wi * (HV / 4) + i;
+          const walk_f4 t = s.stream_weights ? __builtin_nontemporal_load(q) : *q;
+          o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
+        }
+      }
+    };
     for (int r = 0; r < s.rounds; ++r) {
       int pos0[NG], total[NG], nchunk[NG], c[NG];
       int idW[NG], idA[NG], wiA[NG], wi0[NG];
-      float wvW[NG];
+      float wvW[NG][HV];
       auto load_pair = [&](int g, int ck, int& idw, int& wi) {
         idw = 0; wi = -1;
         if (ck * kFeedChunk < total[g]) {
@@ -295,7 +330,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
       for (int g = 0; g < NG; ++g) load_pair(g, 1, idA[g], wiA[g]);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) wvW[g] = wi0[g] >= 0 ? ld_w(wi0[g]) : 0.f;
+      for (int g = 0; g < NG; ++g) ld_w(wi0[g], wvW[g]);
       while (left > 0) {
         // one TURN: every lane group whose ring has room advances by a chunk.  All ring writes first (they
         // use what the previous turn requested: one wait per turn), then all weight requests, then all
@@ -308,10 +343,19 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
           const int gc = chunk_base[g] + c[g];                            // running chunk number of this lane group
           if (gc - __builtin_amdgcn_readlane(done_l, g) >= kFeedRing) continue;   // ring full: the group is still reading
           adv |= 1u << g;
-          int* ring = ring_base + (g0 + g) * 2 * RING;
+          int* ring = ring_base + (g0 + g) * RSTRIDE;
           const int at = (gc % kFeedRing) * kFeedChunk + h;
           ring[at] = idW[g];
-          ring[RING + at] = __float_as_int(wvW[g]);
+          if constexpr (HV == 1) {
+            ring[RING + at] = __float_as_int(wvW[g][0]);
+          } else if constexpr (HV == 2) {
+            *reinterpret_cast<float2*>(ring + RING + at * 2) = make_float2(wvW[g][0], wvW[g][1]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < HV / 4; ++i)
+              *reinterpret_cast<float4*>(ring + RING + at * HV + 4 * i) =
+                  make_float4(wvW[g][4 * i], wvW[g][4 * i + 1], wvW[g][4 * i + 2], wvW[g][4 * i + 3]);
+          }
           lds_st(feed_ready + g0 + g, gc + 1);
         }
         if (adv == 0) {
@@ -324,7 +368,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         for (int g = 0; g < NG; ++g) {
           if (!((adv >> g) & 1)) continue;
           idW[g] = idA[g];
-          wvW[g] = wiA[g] >= 0 ? ld_w(wiA[g]) : 0.f;
+          ld_w(wiA[g], wvW[g]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -354,6 +398,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
   // partial sums, the position in the run, the feeder ring.
   const int l = threadIdx.x % L;
   const int gq = (threadIdx.x / L) % GW;              // lane group inside the wave
+  const int head = H1 ? 0 : l / d4;                    // NV == 1 when HV > 1: the lane's float4 belongs to one head
+  static_assert(H1 || NV == 1, "several heads: one float4 per lane");
   const int n_steps = s.rounds * s.steps;
   for (;;) {
     int t = 0;
@@ -374,14 +420,13 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     }
     pacer.wait_enter(gstep, gstep);
     const int bin = q * GW + gq;
-    float4* accs = lds + (i64)bin * kWalkK * F4;      // [kWalkK][NV][L]
-    const int* ring = ring_base + bin * 2 * RING;
+    float4* accs = lds + (i64)bin * K * F4;           // [K][NV][L]
+    const int* ring = ring_base + bin * RSTRIDE;
     const i64 tb = walk_bin_index_of<GPB>(s, r, bin);
     int total, step_len;
     if (sidx == 0) {                                  // the bin's round starts with this unit
       total = s.bin_cum[tb];
-#pragma unroll
-      for (int k = 0; k < kWalkK; ++k)
+      for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int quad_total = wave_max_int<L>(total);
@@ -433,12 +478,14 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       k_cur = kt;
     };
     struct Meta { int k; float w; };
-    auto consume = [&](const float4 (&x)[SB][NV], const Meta& m) {
+    auto consume = [&](const float4 (&x)[SB][NV], const Meta& m, const float (&wv)[H1 ? 1 : SB]) {
       static_for<SB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         const int kt = group_bcast<L, u>(m.k);
         if (__builtin_expect(kt != k_cur, 0)) row_change(kt);   // group-uniform; about once per batch
-        const float w1 = group_bcast<L, u>(m.w);
+        float w1;
+        if constexpr (H1) w1 = group_bcast<L, u>(m.w);
+        else w1 = wv[u];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           acc[v].x = fmaf(w1, x[u][v].x, acc[v].x);
@@ -467,7 +514,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       const int idw = ring[at];
       m.k = (int)((unsigned)idw >> kWalkKShift);
       off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
-      m.w = __int_as_float(ring[RING + at]);
+      if constexpr (H1) m.w = __int_as_float(ring[RING + at]);
     };
     if (j0 < total && j0 < j1) stage(j0, mc, off_c);
     for (int jb = j0; jb < j1; jb += SB) {
@@ -478,8 +525,19 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
 #pragma unroll
           for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
         });
+        float wv[H1 ? 1 : SB];
+        if constexpr (!H1) {
+          // this batch's weights of the lane's head -- read BEFORE the next batch is staged: entering a new chunk
+          // there hands this batch's chunk back to the feeder (LDS operations of a wave execute in order)
+          const int b0 = (seg_base * kFeedChunk + jb) % RING;    // a batch never wraps (RING % SB == 0)
+#pragma unroll
+          for (int u = 0; u < SB; ++u) wv[u] = __int_as_float(ring[RING + (b0 + u) * HV + head]);
+          asm volatile("" ::: "memory");
+        } else {
+          wv[0] = 0.f;
+        }
         if (jb + SB < total && jb + SB < j1) stage(jb + SB, mn, off_n);
-        consume(x, mc);
+        consume(x, mc, wv);
         mc = mn; off_c = off_n;
       }
     }
@@ -491,8 +549,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       const int n_ch = (total + kFeedChunk - 1) / kFeedChunk;
       if (l == 0) bin_seg[bin] = seg_base + n_ch;
       lds_st(feed_done + bin, seg_base + n_ch);
-      const int my_row = l < kWalkK ? s.bin_rows[tb * kWalkK + l] : -1;
-      for (int k = 0; k < kWalkK; ++k) {
+      const int my_row = l < K ? s.bin_rows[tb * K + l] : -1;
+      for (int k = 0; k < K; ++k) {
         const int rec = __shfl(my_row, k, L);
         if (rec == -1) continue;   // group-uniform
         const i64 row = rec & 0x7fffffff;

@@ -854,14 +854,14 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
 
 // The walk layout of `p` for W windows of win_cols ids and a resident grid of `groups` lane groups
 // (built once per geometry, kept with the plan).  *out = nullptr when the graph does not fit the
-// layout (a bin would hold more than kWalkK rows at every round count tried, sizes beyond 31 bits).
-int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int xcd_slots, hipStream_t st,
+// layout (a bin would hold more than K rows per lane group at every round count tried, sizes beyond 31 bits).
+int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int K, int xcd_slots, hipStream_t st,
                   const Walk** out) {
   auto* vec = (std::vector<Walk>*)p->walks;
   std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
   *out = nullptr;
   for (auto& w : *vec)
-    if (w.W == W && w.win_cols == win_cols && w.groups == groups && w.GW == GW && w.xcd_slots == xcd_slots) {
+    if (w.W == W && w.win_cols == win_cols && w.groups == groups && w.GW == GW && w.K == K && w.xcd_slots == xcd_slots) {
       if (w.rounds > 0) *out = &w;    // rounds == 0: remembered as "does not fit"
       return GRAPHOP_OK;
     }
@@ -872,10 +872,11 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
   }
   const i64 S = p->info.n_segments, E = p->info.n_edges;
   GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E > 0 && E < 0x7fffffffLL && S > 0 &&
-               W >= 1 && groups >= 1 && GW >= 1 && GW <= 4 && groups % GW == 0, "plan_get_walk: plan is not walkable");
+               W >= 1 && groups >= 1 && GW >= 1 && GW <= 4 && groups % GW == 0 && K >= 1 && K <= kWalkK,
+               "plan_get_walk: plan is not walkable");
   Walk wk;
-  wk.W = W; wk.win_cols = win_cols; wk.groups = groups; wk.GW = GW; wk.xcd_slots = xcd_slots; wk.rounds = 0;
-  const int kmax = kWalkK * GW;     // rows per wave bin
+  wk.W = W; wk.win_cols = win_cols; wk.groups = groups; wk.GW = GW; wk.K = K; wk.xcd_slots = xcd_slots; wk.rounds = 0;
+  const int kmax = K * GW;     // rows per wave bin
   const i64 waves = groups / GW;
   auto remember_unfit = [&]() { vec->push_back(wk); return GRAPHOP_OK; };
   if (p->info.max_index >= (1LL << kWalkKShift) || S * (W + 1) >= (i64)1 << 40) return remember_unfit();

@@ -53,6 +53,25 @@ def test_walk_vs_oracle(dev, force_walk, d, blocks):
     assert WALK_KERNELS <= kernels_of(lambda: hip_step(gd, *args))
 
 
+@pytest.mark.parametrize("blocks", [8, 0])
+@pytest.mark.parametrize("h,d", [(8, 32), (4, 16), (2, 32), (4, 32), (8, 16), (2, 128)])
+def test_walk_several_heads_vs_oracle(dev, force_walk, h, d, blocks):
+    """SpMM-type walk kernel with h heads (the reference's (E, h) edge scalars against (N, h, d) rows,
+    graphop_kernel.cu:100-130, 151-163): the feeder waves stage all h weights of a slot, a worker lane reads
+    its head's; fewer rows per lane group where the weight rings take the LDS (256-B rows x 4 heads)."""
+    _lib.tune("walk_blocks", blocks)
+    n = 500 if h * d >= 256 else 1500
+    g = random_graph(n, n + 41, 10 * n, seed=31 + h + d + blocks, chunk_size=32, zero_rows=0.15, hub=900)
+    inp = rand_inputs(g, h, d, seed=9, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+    got = hip_step(gd, *args)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
+    assert "k_spmm_walk_f32" in kernels_of(lambda: hip_step(gd, *args))
+
+
 @pytest.mark.parametrize("drift", [0, 1, 2])
 def test_walk_matches_other_drivers_medium(dev, force_walk, drift):
     """Same inputs through the walk, window-owner and chunk drivers: equal within fp32 re-association;
