@@ -858,6 +858,35 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
   if (S == 0) return GRAPHOP_OK;
   ProfScope prof(BWD ? "softmax_bwd" : "softmax_fwd", st, BWD ? "k_softmax_bwd_seg" : "k_softmax_fwd_seg");
   const bool id = p->info.eid_identity != 0;
+  if constexpr (std::is_same<T, float>::value) {
+    // several heads in storage order: float4 items (kernels_fast.h: softmax_vec4_group)
+    if (id && pow2(h) && h >= 4 && h <= 64 && aligned16(in0) && aligned16(out) && (!BWD || aligned16(in1)) &&
+        kLongSegment * h < 0x7fffffffLL) {
+      const int G = seg_group_width(p->info.n_edges * h / 4 / S, h / 4);
+      const int n_long = (int)p->n_long;
+      const unsigned nb = blocks_for(S, kFastBlock / G) + (unsigned)n_long;
+      const i64 long_len = n_long > 0 ? kLongSegment : (i64)1 << 30;
+      prof.kernel = BWD ? "k_softmax_bwd_vec4" : "k_softmax_fwd_vec4";
+#define GO_V4(GW)                                                                                   \
+  if constexpr (!BWD)                                                                               \
+    hipLaunchKernelGGL((k_softmax_fwd_vec4<GW>), dim3(nb), dim3(kFastBlock), 0, st,                 \
+                       (const i64*)p->seg_chunk, indptr, in0, out, S, (int)h, long_len,             \
+                       (const int*)p->long_segs, n_long, (const i64*)p->row, stats);                \
+  else                                                                                              \
+    hipLaunchKernelGGL((k_softmax_bwd_vec4<GW>), dim3(nb), dim3(kFastBlock), 0, st,                 \
+                       (const i64*)p->seg_chunk, indptr, in0, in1, out, S, (int)h, long_len,        \
+                       (const int*)p->long_segs, n_long);
+      switch (G) {
+        case 8: GO_V4(8) break;
+        case 16: GO_V4(16) break;
+        case 32: GO_V4(32) break;
+        default: GO_V4(64) break;
+      }
+#undef GO_V4
+      GO_LAUNCH_CHECK();
+      return GRAPHOP_OK;
+    }
+  }
   if (pow2(h) && h <= 64) {
     const int G = seg_group_width(p->info.n_edges * h / S, h);
     const int n_long = (int)p->n_long;

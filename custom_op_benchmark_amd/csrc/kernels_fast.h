@@ -1901,6 +1901,353 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
                                        (i64)blockIdx.x - n_long);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Several heads, identity eid, h % 4 == 0, fp32: the (slot, head) items of a row are len * h contiguous
+// floats, read and written as float4s.  Component j of a lane's float4 belongs to head (4 * lane + j) % h
+// for every float4 the lane touches (4 * G % h == 0), so a lane keeps four running statistics and lanes
+// h / 4 apart are merged.  (The scalar form above reads a row of 492 slots x 8 heads twice with 4-byte
+// loads in a latency-bound loop: 2.7 TB/s; this one holds rows up to G * 32 float4s in registers.)
+__device__ __forceinline__ float4 f4_splat(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 f4_max(float4 a, float4 b) {
+  return make_float4(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z, a.w > b.w ? a.w : b.w);
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// exp(a) for a <= 0 (softmax arguments: value - row maximum), full fp32 accuracy without expf's range handling:
+// 2^t * (1 + ln2 * e) with t = fl(a * log2e) and e = the rounding error of that product + a * (log2e's low
+// part).  Arguments below -200 (and the -inf of a padding lane) are clamped there: the result is 0 either way.
+// Six full-rate instructions + one v_exp_f32 instead of expf's fourteen: the multi-head softmax is VALU-bound.
+__device__ __forceinline__ float exp_nonpos(float a) {
+  a = fmaxf(a, -200.f);
+  const float log2e = 1.44269502162933349609375f, log2e_lo = 1.925963033500011e-08f;
+  const float t = a * log2e;
+  const float e = fmaf(a, log2e_lo, fmaf(a, log2e, -t));
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * 0.693147182464599609375f, r);
+}
+__device__ __forceinline__ float4 f4_exp_sub(float4 a, float4 b) {
+  return make_float4(exp_nonpos(a.x - b.x), exp_nonpos(a.y - b.y), exp_nonpos(a.z - b.z), exp_nonpos(a.w - b.w));
+}
+__device__ __forceinline__ float4 f4_rcp(float4 a) { return make_float4(1.f / a.x, 1.f / a.y, 1.f / a.z, 1.f / a.w); }
+template <int G>
+__device__ __forceinline__ float4 f4_shfl_xor(float4 a, int mask) {
+  return make_float4(__shfl_xor(a.x, mask, G), __shfl_xor(a.y, mask, G), __shfl_xor(a.z, mask, G), __shfl_xor(a.w, mask, G));
+}
+// dx = dy * y - g * y
+__device__ __forceinline__ float4 f4_bwd(float4 dy, float4 y, float4 g) {
+  return make_float4(dy.x * y.x - g.x * y.x, dy.y * y.y - g.y * y.y, dy.z * y.z - g.z * y.z, dy.w * y.w - g.w * y.w);
+}
+// online softmax statistics of two partial rows merged: (m, sum) <- (m, sum) + (m2, s2)
+__device__ __forceinline__ void f4_merge(float4& m, float4& sum, float4 m2, float4 s2) {
+  const float4 mn = f4_max(m, m2);
+  sum = f4_add(f4_mul(sum, f4_exp_sub(m, mn)), f4_mul(s2, f4_exp_sub(m2, mn)));
+  m = mn;
+}
+
+constexpr int kVec4CacheFwd = 32;   // float4s per lane held in registers
+constexpr int kVec4CacheBwd = 16;
+
+template <int G, int R4, bool BWD>
+__device__ __forceinline__ void softmax_vec4_regs(const float4* __restrict__ p0, const float4* __restrict__ p1,
+                                                  float4* __restrict__ po, int n4, int l, int hq, float* st_row) {
+    if constexpr (!BWD) {
+      float4 v[R4];
+#pragma unroll
+      for (int r = 0; r < R4; ++r) v[r] = (l + r * G) < n4 ? p0[l + r * G] : f4_splat(-INFINITY);
+      float4 m = f4_splat(-1e9f);
+#pragma unroll
+      for (int r = 0; r < R4; ++r) m = f4_max(m, v[r]);
+#pragma unroll
+      for (int mask = G / 2; mask >= 1; mask >>= 1)
+        if (mask >= hq) m = f4_max(m, f4_shfl_xor<G>(m, mask));
+      float4 sum = f4_splat(0.f);
+#pragma unroll
+      for (int r = 0; r < R4; ++r) {
+        v[r] = (l + r * G) < n4 ? f4_exp_sub(v[r], m) : f4_splat(0.f);
+        sum = f4_add(sum, v[r]);
+      }
+#pragma unroll
+      for (int mask = G / 2; mask >= 1; mask >>= 1)
+        if (mask >= hq) sum = f4_add(sum, f4_shfl_xor<G>(sum, mask));
+      const float4 inv = f4_rcp(sum);              // one division per row and head; items are scaled
+#pragma unroll
+      for (int r = 0; r < R4; ++r)
+        if ((l + r * G) < n4) po[l + r * G] = f4_mul(v[r], inv);
+      if (st_row) {
+        st_row[0] = m.x; st_row[1] = inv.x; st_row[2] = m.y; st_row[3] = inv.y;
+        st_row[4] = m.z; st_row[5] = inv.z; st_row[6] = m.w; st_row[7] = inv.w;
+      }
+    } else {
+      float4 yy[R4], dd[R4];
+      float4 g = f4_splat(0.f);
+#pragma unroll
+      for (int r = 0; r < R4; ++r) {
+        const bool ok = (l + r * G) < n4;
+        yy[r] = ok ? p0[l + r * G] : f4_splat(0.f);
+        dd[r] = ok ? p1[l + r * G] : f4_splat(0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < R4; ++r) g = f4_add(g, f4_mul(dd[r], yy[r]));
+#pragma unroll
+      for (int mask = G / 2; mask >= 1; mask >>= 1)
+        if (mask >= hq) g = f4_add(g, f4_shfl_xor<G>(g, mask));
+#pragma unroll
+      for (int r = 0; r < R4; ++r)
+        if ((l + r * G) < n4) po[l + r * G] = f4_bwd(dd[r], yy[r], g);
+    }
+}
+
+// in0 = x (forward) | y (backward), in1 = dy.  Semantics as softmax_*_seg_body (graphop_kernel.cu:170-230).
+template <int G, bool BWD>
+__device__ __forceinline__ void softmax_vec4_group(
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ in0,
+    const float* __restrict__ in1, float* __restrict__ out, i64 n_seg, int h, i64 long_len, i64 block,
+    const i64* __restrict__ row, float* __restrict__ stats) {
+  constexpr int R4 = BWD ? kVec4CacheBwd : kVec4CacheFwd;
+  const int l = threadIdx.x % G;
+  const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
+  if (s >= n_seg) return;                         // group-uniform
+  const i64 e0 = indptr[seg_chunk[s]];
+  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  if (len > long_len) return;
+  const int n4 = (int)(len * h / 4);
+  const int hq = h / 4;                           // lanes hq apart hold the same heads
+  const float4* p0 = reinterpret_cast<const float4*>(in0 + e0 * h);
+  const float4* p1 = BWD ? reinterpret_cast<const float4*>(in1 + e0 * h) : nullptr;
+  float4* po = reinterpret_cast<float4*>(out + e0 * h);
+  // whole row in registers: inputs read once, one exp per item.  Tiers by row length: the unrolled loops run all
+  // R4 iterations whatever the row holds (a fixed 32 made the pass VALU-bound: 1.8 ms against 1.0 of traffic)
+  float* st_row = (stats && l < hq) ? stats + (row[seg_chunk[s]] * h + 4 * l) * 2 : nullptr;
+  if (n4 <= G * 4) { softmax_vec4_regs<G, 4, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  if (n4 <= G * 8) { softmax_vec4_regs<G, 8, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  if (n4 <= G * 16) { softmax_vec4_regs<G, 16, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  if constexpr (R4 > 16) {
+    if (n4 <= G * R4) { softmax_vec4_regs<G, R4, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  }
+  constexpr int U = 4;
+  if constexpr (!BWD) {
+    float4 m = f4_splat(-1e9f), sum = f4_splat(0.f);
+    for (int q0 = l; q0 < n4; q0 += U * G) {
+      float4 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = (q0 + u * G) < n4 ? p0[q0 + u * G] : f4_splat(-INFINITY);
+      float4 mb = m;
+#pragma unroll
+      for (int u = 0; u < U; ++u) mb = f4_max(mb, t[u]);
+      sum = f4_mul(sum, f4_exp_sub(m, mb));
+#pragma unroll
+      for (int u = 0; u < U; ++u) sum = f4_add(sum, f4_exp_sub(t[u], mb));   // exp(-inf) = 0 past the end
+      m = mb;
+    }
+#pragma unroll
+    for (int mask = G / 2; mask >= 1; mask >>= 1)
+      if (mask >= hq) f4_merge(m, sum, f4_shfl_xor<G>(m, mask), f4_shfl_xor<G>(sum, mask));
+    const float4 inv = f4_rcp(sum);
+    for (int q0 = l; q0 < n4; q0 += U * G) {
+      float4 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = (q0 + u * G) < n4 ? p0[q0 + u * G] : f4_splat(0.f);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((q0 + u * G) < n4) po[q0 + u * G] = f4_mul(f4_exp_sub(t[u], m), inv);
+    }
+    if (stats && l < hq) {
+      float* o = stats + (row[seg_chunk[s]] * h + 4 * l) * 2;
+      o[0] = m.x; o[1] = inv.x; o[2] = m.y; o[3] = inv.y;
+      o[4] = m.z; o[5] = inv.z; o[6] = m.w; o[7] = inv.w;
+    }
+  } else {
+    float4 g = f4_splat(0.f);
+    for (int q0 = l; q0 < n4; q0 += U * G) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((q0 + u * G) < n4) g = f4_add(g, f4_mul(p1[q0 + u * G], p0[q0 + u * G]));
+    }
+#pragma unroll
+    for (int mask = G / 2; mask >= 1; mask >>= 1)
+      if (mask >= hq) g = f4_add(g, f4_shfl_xor<G>(g, mask));
+    for (int q0 = l; q0 < n4; q0 += U * G) {
+      float4 ty[U], td[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = (q0 + u * G) < n4;
+        ty[u] = ok ? p0[q0 + u * G] : f4_splat(0.f);
+        td[u] = ok ? p1[q0 + u * G] : f4_splat(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((q0 + u * G) < n4) po[q0 + u * G] = f4_bwd(td[u], ty[u], g);
+    }
+  }
+}
+
+// A workgroup's row held in registers (up to 256 * R4 float4s): inputs read once, one exp per item -- every thread
+// exponentiates against its OWN maximum, the (max, sum) pairs are merged through LDS, and the items are rescaled
+// by exp(own max - row max) / row sum.
+template <int R4, bool BWD>
+__device__ __forceinline__ void softmax_vec4_long_regs(const float4* __restrict__ p0, const float4* __restrict__ p1,
+                                                       float4* __restrict__ po, int n4, int hq, float4* sh_m,
+                                                       float4* sh_s, float* st_row) {
+  const int tid = threadIdx.x;
+  float4 a[R4], b[BWD ? R4 : 1];
+#pragma unroll
+  for (int r = 0; r < R4; ++r) {
+    const bool ok = (tid + r * kFastBlock) < n4;
+    a[r] = ok ? p0[tid + r * kFastBlock] : f4_splat(BWD ? 0.f : -INFINITY);
+    if constexpr (BWD) b[r] = ok ? p1[tid + r * kFastBlock] : f4_splat(0.f);
+  }
+  float4 m = f4_splat(-1e9f), sum = f4_splat(0.f);
+  if constexpr (!BWD) {
+#pragma unroll
+    for (int r = 0; r < R4; ++r) m = f4_max(m, a[r]);
+#pragma unroll
+    for (int r = 0; r < R4; ++r) {
+      a[r] = f4_exp_sub(a[r], m);                 // 0 for the -inf of a padding slot
+      sum = f4_add(sum, a[r]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R4; ++r) sum = f4_add(sum, f4_mul(b[r], a[r]));
+  }
+  sh_m[tid] = m; sh_s[tid] = sum;
+  __syncthreads();
+  for (int stride = kFastBlock / 2; stride >= hq; stride >>= 1) {
+    if (tid < stride) {
+      if constexpr (!BWD) {
+        float4 x = sh_m[tid], y = sh_s[tid];
+        f4_merge(x, y, sh_m[tid + stride], sh_s[tid + stride]);
+        sh_m[tid] = x; sh_s[tid] = y;
+      } else {
+        sh_s[tid] = f4_add(sh_s[tid], sh_s[tid + stride]);
+      }
+    }
+    __syncthreads();
+  }
+  const float4 M = sh_m[tid % hq], S = sh_s[tid % hq];
+  if constexpr (!BWD) {
+    const float4 inv = f4_rcp(S);
+    const float4 c = f4_mul(f4_exp_sub(m, M), inv);
+#pragma unroll
+    for (int r = 0; r < R4; ++r)
+      if ((tid + r * kFastBlock) < n4) po[tid + r * kFastBlock] = f4_mul(a[r], c);
+    if (st_row) {
+      st_row[0] = M.x; st_row[1] = inv.x; st_row[2] = M.y; st_row[3] = inv.y;
+      st_row[4] = M.z; st_row[5] = inv.z; st_row[6] = M.w; st_row[7] = inv.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R4; ++r)
+      if ((tid + r * kFastBlock) < n4) po[tid + r * kFastBlock] = f4_bwd(b[r], a[r], S);
+  }
+}
+
+// Rows above long_len slots: one workgroup per row, float4 items, statistics merged through LDS.
+template <bool BWD>
+__device__ __forceinline__ void softmax_vec4_long(
+    const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ out, int h,
+    float4* sh_m, float4* sh_s, i64 long_len, const i64* __restrict__ row, float* __restrict__ stats) {
+  const i64 s = long_segs[blockIdx.x];
+  const i64 e0 = indptr[seg_chunk[s]];
+  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  if (len <= long_len) return;                    // block-uniform: the per-row groups take it
+  const i64 n4 = len * h / 4;
+  const int tid = threadIdx.x, hq = h / 4;
+  const float4* p0 = reinterpret_cast<const float4*>(in0 + e0 * h);
+  const float4* p1 = BWD ? reinterpret_cast<const float4*>(in1 + e0 * h) : nullptr;
+  float4* po = reinterpret_cast<float4*>(out + e0 * h);
+  if (n4 <= 16 * kFastBlock) {                    // block-uniform
+    float* st_row = (!BWD && stats && tid < hq) ? stats + (row[seg_chunk[s]] * h + 4 * tid) * 2 : nullptr;
+    if (n4 <= 8 * kFastBlock) softmax_vec4_long_regs<8, BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
+    else softmax_vec4_long_regs<16, BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
+    return;
+  }
+  constexpr int U = 4;
+  float4 m = f4_splat(-1e9f), sum = f4_splat(0.f);
+  for (i64 q0 = tid; q0 < n4; q0 += U * kFastBlock) {
+    if constexpr (!BWD) {
+      float4 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = (q0 + u * kFastBlock) < n4 ? p0[q0 + u * kFastBlock] : f4_splat(-INFINITY);
+      float4 mb = m;
+#pragma unroll
+      for (int u = 0; u < U; ++u) mb = f4_max(mb, t[u]);
+      sum = f4_mul(sum, f4_exp_sub(m, mb));
+#pragma unroll
+      for (int u = 0; u < U; ++u) sum = f4_add(sum, f4_exp_sub(t[u], mb));
+      m = mb;
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((q0 + u * kFastBlock) < n4) sum = f4_add(sum, f4_mul(p1[q0 + u * kFastBlock], p0[q0 + u * kFastBlock]));
+    }
+  }
+  sh_m[tid] = m; sh_s[tid] = sum;
+  __syncthreads();
+  for (int stride = kFastBlock / 2; stride >= hq; stride >>= 1) {   // tid and tid + stride hold the same heads
+    if (tid < stride) {
+      if constexpr (!BWD) {
+        float4 a = sh_m[tid], b = sh_s[tid];
+        f4_merge(a, b, sh_m[tid + stride], sh_s[tid + stride]);
+        sh_m[tid] = a; sh_s[tid] = b;
+      } else {
+        sh_s[tid] = f4_add(sh_s[tid], sh_s[tid + stride]);
+      }
+    }
+    __syncthreads();
+  }
+  m = sh_m[tid % hq]; sum = sh_s[tid % hq];
+  const float4 inv = BWD ? sum : f4_rcp(sum);
+  for (i64 q0 = tid; q0 < n4; q0 += U * kFastBlock) {
+    float4 t0[U], t1[BWD ? U : 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = (q0 + u * kFastBlock) < n4;
+      t0[u] = ok ? p0[q0 + u * kFastBlock] : f4_splat(0.f);
+      if constexpr (BWD) t1[u] = ok ? p1[q0 + u * kFastBlock] : f4_splat(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((q0 + u * kFastBlock) < n4) {
+        if constexpr (!BWD) po[q0 + u * kFastBlock] = f4_mul(f4_exp_sub(t0[u], m), inv);
+        else po[q0 + u * kFastBlock] = f4_bwd(t1[u], t0[u], sum);
+      }
+  }
+  if constexpr (!BWD) {
+    if (stats && tid < hq) {
+      float* o = stats + (row[seg_chunk[s]] * h + 4 * tid) * 2;
+      o[0] = m.x; o[1] = inv.x; o[2] = m.y; o[3] = inv.y;
+      o[4] = m.z; o[5] = inv.z; o[6] = m.w; o[7] = inv.w;
+    }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_vec4(
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ x,
+    float* __restrict__ y, i64 n_seg, int h, i64 long_len, const int* __restrict__ long_segs, int n_long,
+    const i64* __restrict__ row, float* __restrict__ stats) {
+  __shared__ float4 sh_m[kFastBlock];
+  __shared__ float4 sh_s[kFastBlock];
+  if ((int)blockIdx.x < n_long)
+    softmax_vec4_long<false>(long_segs, seg_chunk, indptr, x, nullptr, y, h, sh_m, sh_s, long_len, row, stats);
+  else
+    softmax_vec4_group<G, false>(seg_chunk, indptr, x, nullptr, y, n_seg, h, long_len, (i64)blockIdx.x - n_long, row, stats);
+}
+
+template <int G>
+__global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_vec4(
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ y,
+    const float* __restrict__ dy, float* __restrict__ dx, i64 n_seg, int h, i64 long_len,
+    const int* __restrict__ long_segs, int n_long) {
+  __shared__ float4 sh_m[kFastBlock];
+  __shared__ float4 sh_s[kFastBlock];
+  if ((int)blockIdx.x < n_long)
+    softmax_vec4_long<true>(long_segs, seg_chunk, indptr, y, dy, dx, h, sh_m, sh_s, long_len, nullptr, nullptr);
+  else
+    softmax_vec4_group<G, true>(seg_chunk, indptr, y, dy, dx, n_seg, h, long_len, (i64)blockIdx.x - n_long, nullptr, nullptr);
+}
+
 // Any h (G need not be a multiple of h): heads in an outer loop, strided reads.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_seg_anyh(

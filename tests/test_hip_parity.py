@@ -500,6 +500,35 @@ def test_softmax_long_rows_and_cached_rows(dev, h):
     assert _lib.get_plan(g.row.to(dev), g.ptr_r.to(dev), g.eid_r.to(dev)).info.max_segment_len > 8192  # > 256*32 items: loop path
 
 
+@pytest.mark.parametrize("h", [4, 8, 16, 64])
+def test_softmax_several_heads_float4_items(dev, h):
+    """h % 4 == 0 heads in storage order take the float4 kernels (kernels_fast.h: softmax_vec4_group): rows held in
+    registers (up to G * 32 / G * 16 float4s forward / backward), rows looped over twice, hub rows one workgroup
+    each, empty rows; the column-major orientation (gathered through eid) stays on the scalar kernels."""
+    gen = torch.Generator().manual_seed(40 + h)
+    lens = torch.cat([torch.randint(0, 40, (300,), generator=gen), torch.randint(250, 400, (20,), generator=gen),
+                      torch.randint(700, 1024, (12,), generator=gen), torch.tensor([1025, 2000, 5000, 0, 1, 1024])])
+    lens = lens[torch.randperm(len(lens), generator=gen)]
+    n = len(lens)
+    src = torch.repeat_interleave(torch.arange(n), lens)
+    dst = torch.randint(0, n, (int(lens.sum()),), generator=gen)
+    g = graphs.graph_from_coo(src, dst, n, n, chunk_size=32)
+    x = torch.randn(g.n_edges, h, generator=gen) * 3
+    ge = torch.randn(g.n_edges, h, generator=gen)
+    for a3, want_kernel in (((g.row, g.ptr_r, g.eid_r), "vec4"), ((g.col, g.ptr_c, g.eid_c), "seg")):
+        a3d = tuple(v.to(dev) for v in a3)
+        yo = oracle.sparse_softmax_forward(*a3, x)
+        _lib.profile_enable(True)
+        y = ops.sparse_softmax_forward(*a3d, x.to(dev))
+        dx = ops.sparse_softmax_backward(*a3d, y, ge.to(dev))
+        torch.cuda.synchronize()
+        ran = {r.get("kernel") for r in _lib.profile_read().values()}
+        _lib.profile_enable(False)
+        assert {k for k in ran if "softmax" in k} == {"k_softmax_fwd_" + want_kernel, "k_softmax_bwd_" + want_kernel}, ran
+        close(y, yo)
+        close(dx, oracle.sparse_softmax_backward(*a3, yo, ge), rtol=1e-3, atol=1e-6)
+
+
 def test_scalar_transpose_path_matches(dev, force_sweep):
     """Optional column-major path (off by default): per-slot scalars transposed by a paced scatter
     before the SpMM; must give the same dB / dx as the gather path."""
