@@ -332,8 +332,15 @@ namespace {
 
 // Which window-owner passes take the dealt layout + staged ids (also what graphop_plan_prepare builds).
 inline bool table_off32(i64 n_table_rows, int L, int NV) { return n_table_rows * 16LL * L * NV < (1LL << 32); }
+// several heads: one float4 per lane, a head = 4 / 8 / 16 / 32 lanes (kernels_fast.h: sddmm_strip_staged_heads)
+inline bool sddmm_staged_heads(int L, int NV, i64 h, i64 n_edges) {
+  if (h < 2 || NV != 1 || L < 16 || L % h != 0 || n_edges * h >= 0x7fffffffLL) return false;
+  const i64 d4 = L / h;
+  return d4 == 4 || d4 == 8 || d4 == 16 || d4 == 32;
+}
 inline bool sddmm_staged(const graphop_plan* plan, int L, int NV, i64 h, i64 n_table_rows) {
-  return (tuning().staged_ids & 1) && h == 1 && plan->info.eid_identity && table_off32(n_table_rows, L, NV);
+  return (tuning().staged_ids & 1) && (h == 1 || sddmm_staged_heads(L, NV, h, plan->info.n_edges)) &&
+         plan->info.eid_identity && table_off32(n_table_rows, L, NV);
 }
 inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
   return (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
@@ -551,7 +558,21 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   const float* b = (const float*)B;
   float* yy = (float*)y;
   if (staged) {
-    hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+    if (h == 1) {
+      hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+    } else if constexpr (NV == 1 && L >= 16) {
+      auto go = [&](auto dc) {
+        constexpr int D4 = decltype(dc)::value;
+        if constexpr (D4 < L)
+          hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV, D4>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+      };
+      switch (d4) {
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 8: go(std::integral_constant<int, 8>{}); break;
+        case 16: go(std::integral_constant<int, 16>{}); break;
+        default: go(std::integral_constant<int, 32>{}); break;
+      }
+    }
     return 1;
   }
 #define GO_K(H1, ID, O32)                                                                          \

@@ -671,6 +671,112 @@ __device__ __forceinline__ void sddmm_strip_staged(const float4* __restrict__ ro
   flush_results();
 }
 
+// Several heads: a head's d floats lie in D4 = d / 4 consecutive lanes.  p[u] = this lane's partial of slot u's
+// dot products (16 slots); on return r[i] = the total of slot R * (l % min(D4, 16)) + i for the lane's head,
+// R = 16 / min(D4, 16) -- the transpose-reduce of group_dots_to_owner, stopped at the head's width.
+template <int D4>
+__device__ __forceinline__ void heads_dots_to_owners(float (&p)[16], int l, float (&r)[16 / (D4 < 16 ? D4 : 16)]) {
+  static_assert(D4 == 4 || D4 == 8 || D4 == 16 || D4 == 32, "lanes per head");
+  if constexpr (D4 >= 16) {
+    float v = group_dots_to_owner<16, 16>(p, l);
+    if constexpr (D4 == 32) v += __shfl_xor(v, 16);
+    r[0] = v;
+  } else if constexpr (D4 == 8) {
+    float t8[8], t4[4];
+    const bool b2 = l & 4, b1 = l & 2, b0 = l & 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float keep = b2 ? p[u + 8] : p[u], send = b2 ? p[u] : p[u + 8];
+      t8[u] = keep + dpp_f32<0x141>(send);      // row_half_mirror = lane ^ 7
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float keep = b1 ? t8[u + 4] : t8[u], send = b1 ? t8[u] : t8[u + 4];
+      t4[u] = keep + dpp_f32<0x4E>(send);       // lane ^ 2
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float keep = b0 ? t4[u + 2] : t4[u], send = b0 ? t4[u] : t4[u + 2];
+      r[u] = keep + dpp_f32<0xB1>(send);        // lane ^ 1
+    }
+  } else {
+    float t8[8];
+    const bool b1 = l & 2, b0 = l & 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float keep = b1 ? p[u + 8] : p[u], send = b1 ? p[u] : p[u + 8];
+      t8[u] = keep + dpp_f32<0x4E>(send);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float keep = b0 ? t8[u + 4] : t8[u], send = b0 ? t8[u] : t8[u + 4];
+      r[u] = keep + dpp_f32<0xB1>(send);
+    }
+  }
+}
+
+// Staged SDDMM strip for H = L / D4 heads (identity eid, 32-bit offsets, dealt layout, one float4 per lane):
+// y[e * H + head] = <A_k[head], B[idx[e]][head]>  (graphop_kernel.cu:40-55, :135-149).  A batch's 16 x H results
+// end up R per lane and leave in R store instructions behind the next batch's row requests (the unstaged strip
+// stores per slot: 16 store instructions between two batches of row requests).
+template <int L, int D4, typename Stage>
+__device__ __forceinline__ void sddmm_strip_staged_heads(const float4* __restrict__ rowsA, int lo_l, int n_l,
+                                                         int pos0, const int* __restrict__ ids_w,
+                                                         int* __restrict__ idbuf, const float* __restrict__ B,
+                                                         float* __restrict__ y, int l, Stage&& stage_rows) {
+  constexpr int SB = 16, H = L / D4, R = 16 / (D4 < 16 ? D4 : 16);
+  static_assert(StripCfg<L, 1>::SB == SB && L % D4 == 0 && H >= 2, "16-slot batches, whole heads");
+  constexpr i64 F4 = L;
+  StripMap m;
+  m.init<L>(lo_l, n_l, l);
+  if (m.total == 0) return;
+  IdStage<L, 1> ids;
+  ids.init(ids_w, nullptr, pos0, idbuf, l, m.total);
+  stage_rows();
+  const int head = l / D4;
+  const int slot0 = R * (l % (D4 < 16 ? D4 : 16));          // first of the R slots whose totals this lane receives
+  const bool owner = D4 <= 16 || (l & 16) == 0;             // 32 lanes per head: both 16-lane rows hold the total
+  float held[R];
+  i64 held_at[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) { held[i] = 0.f; held_at[i] = -1; }
+  const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
+  for (int jb = 0; jb < m.total; jb += SB) {
+    const int nb = (m.total - jb) < SB ? (m.total - jb) : SB;
+    ids.advance(jb);
+    const int j = (jb + l) < m.total ? jb + l : m.total - 1;   // lanes past the end re-read the last slot
+    const int nsrc = ids.id(j);
+    int nk, e;
+    m.locate<L>(j, nk, e);
+    const int my_e = (l < nb) ? e : -1;
+    const unsigned my_koff = (unsigned)nk * (unsigned)(F4 * 16);
+    const unsigned my_off = (unsigned)nsrc * (unsigned)(F4 * 16);
+    float4 b[SB];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      b[u] = ld4_off(B, group_bcast<L, u>(my_off) + (unsigned)(l * 16));
+    });
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+      if (held_at[i] >= 0) y[held_at[i]] = held[i];          // the previous batch's results, behind the row requests
+    float part[SB];
+    static_for<SB>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const unsigned ko = group_bcast<L, u>(my_koff);
+      part[u] = dot4(*reinterpret_cast<const float4*>(lds_l + ko), b[u]);
+    });
+    heads_dots_to_owners<D4>(part, l, held);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int es = __shfl(my_e, slot0 + i, L);
+      held_at[i] = (es >= 0 && owner) ? (i64)es * H + head : -1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (held_at[i] >= 0) y[held_at[i]] = held[i];
+}
+
 // `sink(k, acc)` receives the finished partial sum of granule k (group-uniform call).
 template <int L, int NV, bool H1, bool EID_ID, bool OFF32, typename Sink>
 __device__ __forceinline__ void spmm_strip(Sink&& sink, int lo_l, int n_l,
@@ -1249,8 +1355,9 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, H1, true)) void k_sddmm_w
 
 // Staged form (h == 1, identity eid, table < 4 GiB, dealt layout in the view): tasks come with their
 // granules already dealt, ids through the group's LDS buffer (behind the A rows in dynamic LDS).
-template <int L, int NV>
-__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, true, true)) void k_sddmm_wown_staged_f32(
+// D4 > 0: L / D4 heads of D4 float4s each (NV == 1).
+template <int L, int NV, int D4 = 0>
+__global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, D4 == 0, true)) void k_sddmm_wown_staged_f32(
     SweepView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y) {
   extern __shared__ float4 lds[];
   constexpr i64 F4 = (i64)L * NV;
@@ -1282,8 +1389,12 @@ __global__ __launch_bounds__(kFastBlock, sweep_bpc(NV, true, true)) void k_sddmm
         for (int v = 0; v < NV; ++v) mine[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
       }
     };
-    sddmm_strip_staged<L, NV>(mine, cur.lo, cur.hi - cur.lo, __shfl(cur.pos, 0, L), s.ids_w, idbuf, B, y, l,
-                              stage_rows);
+    if constexpr (D4 == 0)
+      sddmm_strip_staged<L, NV>(mine, cur.lo, cur.hi - cur.lo, __shfl(cur.pos, 0, L), s.ids_w, idbuf, B, y, l,
+                                stage_rows);
+    else
+      sddmm_strip_staged_heads<L, D4>(mine, cur.lo, cur.hi - cur.lo, __shfl(cur.pos, 0, L), s.ids_w, idbuf, B, y, l,
+                                      stage_rows);
     cur = nxt;
     more = more_n;
   }

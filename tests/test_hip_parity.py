@@ -421,6 +421,32 @@ def test_id_staging_on_and_off_vs_oracle(dev, force_sweep, d, staged):
         _lib.tune_reset(); _lib.clear_plan_cache()
 
 
+@pytest.mark.parametrize("h,d", [(8, 32), (4, 16), (2, 32), (8, 16), (4, 64), (2, 128), (2, 64), (4, 32)])
+def test_staged_sddmm_several_heads_vs_oracle(dev, force_sweep, h, d):
+    """Window-owner SDDMM-type passes with several heads on the dealt layout (kernels_fast.h:
+    sddmm_strip_staged_heads): a head = 4 / 8 / 16 / 32 lanes of the row's lane group; the 16 x h results of a
+    batch leave in 16 / min(lanes per head, 16) store instructions.  Row- and column-orientation consumers of
+    the scores (softmax, SpMM) check every (edge, head) position."""
+    _lib.tune("sweep_bpc", 1 if h * d <= 64 else 3)
+    _lib.tune("window_kb", 4 * max(1, h * d // 64)); _lib.clear_plan_cache()
+    n = 700 if h * d >= 256 else 1500
+    g = random_graph(n, n + 41, 10 * n, seed=h * 7 + d, chunk_size=32, zero_rows=0.15, hub=900)
+    inp = rand_inputs(g, h, d, seed=8, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+    got = hip_step(gd, *args)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k])
+    _lib.profile_enable(True)
+    hip_step(gd, *args)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_staged_f32", prof["sddmm_fwd"]
+    assert prof["spmm_bwd_dedata"]["kernel"] == "k_sddmm_wown_staged_f32", prof["spmm_bwd_dedata"]
+
+
 @pytest.mark.parametrize("k", [1, 4])
 @pytest.mark.parametrize("deg", [15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200])
 def test_staged_strips_at_segment_boundaries(dev, force_sweep, deg, k):
