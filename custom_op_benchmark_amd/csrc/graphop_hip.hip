@@ -224,6 +224,10 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   } else if (!force_windows && t.sweep_w <= 0 && coarse > 1) {
     const i64 Wc = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024 * coarse));
     if (Wc >= 2) W = Wc; else coarse = 1;
+  } else if (!force_windows && t.sweep_w <= 0 && !accumulating && !(opts && opts->window_scale > 0) && row_bytes >= 1024) {
+    // 1-KB rows: 4 MB windows leave a (row, window) granule with half a batch of slots and one A-row fetch per
+    // 8 gathered rows; windows of twice the L2 size measure 7 % faster (Reddit-shape d = 256: 8.08 -> 7.49 ms)
+    while (W > 2 && mean_row < 12 * W) W >>= 1;
   }
   if (W < 2 || W > t.max_windows) return 0;
   const i64 win_cols = ceil_div(n_table_rows, W);
@@ -417,7 +421,9 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int w
     if (pi.max_index >= (1LL << kWalkKShift)) return 0;
     const i64 table_bytes = n_table_rows * 16LL * L * NV;
     if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
-    const i64 win_kb = pi.eid_identity ? t.walk_window_kb : t.walk_window_kb_col;
+    // column-major passes: 2 MB windows at 256-B rows (the scalar lines share the L2), 4 MB from 1-KB rows on
+    // (Reddit-shape d = 256: 9.42 -> 8.83 ms; d = 128 is best at 2 MB)
+    const i64 win_kb = pi.eid_identity ? t.walk_window_kb : (16LL * L * NV >= 1024 ? 2 * (i64)t.walk_window_kb_col : t.walk_window_kb_col);
     i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes, (win_kb > 0 ? win_kb : 1) * 1024));
     if (W < 2) W = 2;
     if (W > t.max_windows || W > 512) return 0;
@@ -548,7 +554,8 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   const bool id = plan->info.eid_identity != 0;
   const bool off32 = table_off32(n_table_rows, L, NV);   // table < 4 GiB: 32-bit byte offsets
   so.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
-  so.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int);
+  so.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int) + (h > 1 ? 64 * (int)h : 0);   // + [16 slots][h] results
+  if (h > 1 && !aligned16(y)) so.staged = false;
   const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
   if (use != 1) return use;
   const bool staged = sl.window_owner && sl.view.rec != nullptr;
@@ -1213,7 +1220,7 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
     o.dry_run = 1;
     o.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
     o.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
-    o.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int);
+    o.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int) + (h > 1 ? 64 * (int)h : 0);
     rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/false, &o);
     o.staged = spmm_staged(L, NV, h, n_table_rows);
     if (rc >= 0) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &o);
