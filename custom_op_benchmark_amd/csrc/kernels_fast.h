@@ -1737,20 +1737,21 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
     T sum = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      v[r] = (l + (i64)r * G) < items ? exp_t(v[r] - m) : (T)0;
+      v[r] = (l + (i64)r * G) < items ? exp_le0(v[r] - m) : (T)0;
       sum += v[r];
     }
 #pragma unroll
     for (int mask = G / 2; mask >= 1; mask >>= 1)
       if (mask >= h) sum += __shfl_xor(sum, mask, G);
+    const T inv = (T)1 / sum;                     // one division per row; the items are scaled
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const i64 q = l + (i64)r * G;
-      if (q < items) y[offs(q)] = v[r] / sum;
+      if (q < items) y[offs(q)] = v[r] * inv;
     }
     if (stats && l < h) {   // row statistics for the fused attention backward: (max, 1 / sum)
       const i64 o = (row[seg_chunk[s]] * h + l) * 2;
-      stats[o] = m; stats[o + 1] = (T)1 / sum;
+      stats[o] = m; stats[o + 1] = inv;
     }
     return;
   }
@@ -1760,10 +1761,10 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
     const i64 k = e0 + q / h;
     const T v = x[(EID_ID ? k : eid[k]) * h + t];
     if (v > m) {
-      sum = sum * exp_t(m - v) + (T)1;
+      sum = sum * exp_le0(m - v) + (T)1;
       m = v;
     } else {
-      sum += exp_t(v - m);
+      sum += exp_le0(v - m);
     }
   }
 #pragma unroll
@@ -1772,18 +1773,19 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
       const T m2 = __shfl_xor(m, mask, G);
       const T s2 = __shfl_xor(sum, mask, G);
       const T mn = m > m2 ? m : m2;
-      sum = sum * exp_t(m - mn) + s2 * exp_t(m2 - mn);
+      sum = sum * exp_le0(m - mn) + s2 * exp_le0(m2 - mn);
       m = mn;
     }
   }
+  const T inv = (T)1 / sum;
   for (i64 q = l; q < items; q += G) {
     const i64 k = e0 + q / h;
     const i64 o = (EID_ID ? k : eid[k]) * h + t;
-    y[o] = exp_t(x[o] - m) / sum;
+    y[o] = exp_le0(x[o] - m) * inv;
   }
   if (stats && l < h) {
     const i64 o = (row[seg_chunk[s]] * h + l) * 2;
-    stats[o] = m; stats[o + 1] = (T)1 / sum;
+    stats[o] = m; stats[o + 1] = inv;
   }
 }
 
@@ -1888,7 +1890,7 @@ __device__ __forceinline__ void block_merge(T& m, T& sum, T* sh_m, T* sh_s, int 
       if constexpr (!BWD) {
         const T m1 = sh_m[tid], m2 = sh_m[tid + stride];
         const T mn = m1 > m2 ? m1 : m2;
-        sh_s[tid] = sh_s[tid] * exp_t(m1 - mn) + sh_s[tid + stride] * exp_t(m2 - mn);
+        sh_s[tid] = sh_s[tid] * exp_le0(m1 - mn) + sh_s[tid + stride] * exp_le0(m2 - mn);
         sh_m[tid] = mn;
       } else {
         sh_s[tid] += sh_s[tid + stride];
@@ -1953,22 +1955,23 @@ __device__ __forceinline__ void softmax_long_body(
       m = sh_m[t];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        v[r] = (tid + r * kFastBlock) < n_it ? exp_t(v[r] - m) : (T)0;
+        v[r] = (tid + r * kFastBlock) < n_it ? exp_le0(v[r] - m) : (T)0;
         sum += v[r];
       }
       T mm = 0;
       block_merge<T, true>(mm, sum, sh_m, sh_s, h);
+      const T inv = (T)1 / sum;
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         const int q = tid + r * kFastBlock;
         if (q < n_it) {
-          if constexpr (EID_ID) po[r * kFastBlock] = v[r] / sum;
-          else out[offs(q)] = v[r] / sum;
+          if constexpr (EID_ID) po[r * kFastBlock] = v[r] * inv;
+          else out[offs(q)] = v[r] * inv;
         }
       }
       if (stats && tid < h) {
         const i64 o = (row[seg_chunk[s]] * h + tid) * 2;
-        stats[o] = m; stats[o + 1] = (T)1 / sum;
+        stats[o] = m; stats[o + 1] = inv;
       }
     } else {
 #pragma unroll
@@ -1990,22 +1993,23 @@ __device__ __forceinline__ void softmax_long_body(
     const i64 o = offs(q);
     if constexpr (!BWD) {
       const T v = in0[o];
-      if (v > m) { sum = sum * exp_t(m - v) + (T)1; m = v; }
-      else sum += exp_t(v - m);
+      if (v > m) { sum = sum * exp_le0(m - v) + (T)1; m = v; }
+      else sum += exp_le0(v - m);
     } else {
       sum += in1[o] * in0[o];
     }
   }
   block_merge<T, BWD>(m, sum, sh_m, sh_s, h);
+  const T inv = BWD ? sum : (T)1 / sum;
   for (i64 q = tid; q < items; q += kFastBlock) {
     const i64 o = offs(q);
-    if constexpr (!BWD) out[o] = exp_t(in0[o] - m) / sum;
+    if constexpr (!BWD) out[o] = exp_le0(in0[o] - m) * inv;
     else { const T yy = in0[o]; out[o] = in1[o] * yy - sum * yy; }
   }
   if constexpr (!BWD) {
     if (stats && tid < h) {
       const i64 o = (row[seg_chunk[s]] * h + tid) * 2;
-      stats[o] = m; stats[o + 1] = (T)1 / sum;
+      stats[o] = m; stats[o + 1] = inv;
     }
   }
 }
@@ -2055,18 +2059,6 @@ __device__ __forceinline__ float4 f4_max(float4 a, float4 b) {
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-// exp(a) for a <= 0 (softmax arguments: value - row maximum), full fp32 accuracy without expf's range handling:
-// 2^t * (1 + ln2 * e) with t = fl(a * log2e) and e = the rounding error of that product + a * (log2e's low
-// part).  Arguments below -200 (and the -inf of a padding lane) are clamped there: the result is 0 either way.
-// Six full-rate instructions + one v_exp_f32 instead of expf's fourteen: the multi-head softmax is VALU-bound.
-__device__ __forceinline__ float exp_nonpos(float a) {
-  a = fmaxf(a, -200.f);
-  const float log2e = 1.44269502162933349609375f, log2e_lo = 1.925963033500011e-08f;
-  const float t = a * log2e;
-  const float e = fmaf(a, log2e_lo, fmaf(a, log2e, -t));
-  const float r = __builtin_amdgcn_exp2f(t);
-  return fmaf(r, e * 0.693147182464599609375f, r);
-}
 __device__ __forceinline__ float4 f4_exp_sub(float4 a, float4 b) {
   return make_float4(exp_nonpos(a.x - b.x), exp_nonpos(a.y - b.y), exp_nonpos(a.z - b.z), exp_nonpos(a.w - b.w));
 }
