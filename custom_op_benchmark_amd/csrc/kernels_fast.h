@@ -1718,16 +1718,19 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
     if constexpr (EID_ID) return e0 * h + q;
     else return eid[e0 + q / h] * h + t;
   };
-  if (items <= (i64)G * R) {   // whole row in registers: x read once, one exp per item
-    T v[R];
+  // whole row in registers: x read once, one exp per item.  Tiers by row length: the unrolled loops run all RR
+  // iterations whatever the row holds
+  auto in_regs = [&](auto rc) {
+    constexpr int RR = decltype(rc)::value;
+    T v[RR];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const i64 q = l + (i64)r * G;
       v[r] = q < items ? x[offs(q)] : neg_inf<T>();
     }
     T m = (T)-1e9;
 #pragma unroll
-    for (int r = 0; r < R; ++r) m = v[r] > m ? v[r] : m;
+    for (int r = 0; r < RR; ++r) m = v[r] > m ? v[r] : m;
 #pragma unroll
     for (int mask = G / 2; mask >= 1; mask >>= 1)
       if (mask >= h) {
@@ -1736,7 +1739,7 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
       }
     T sum = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       v[r] = (l + (i64)r * G) < items ? exp_le0(v[r] - m) : (T)0;
       sum += v[r];
     }
@@ -1745,7 +1748,7 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
       if (mask >= h) sum += __shfl_xor(sum, mask, G);
     const T inv = (T)1 / sum;                     // one division per row; the items are scaled
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const i64 q = l + (i64)r * G;
       if (q < items) y[offs(q)] = v[r] * inv;
     }
@@ -1753,8 +1756,10 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
       const i64 o = (row[seg_chunk[s]] * h + l) * 2;
       stats[o] = m; stats[o + 1] = inv;
     }
-    return;
-  }
+  };
+  if (items <= (i64)G * (R / 4)) { in_regs(std::integral_constant<int, R / 4>{}); return; }
+  if (items <= (i64)G * (R / 2)) { in_regs(std::integral_constant<int, R / 2>{}); return; }
+  if (items <= (i64)G * R) { in_regs(std::integral_constant<int, R>{}); return; }
 
   T m = (T)-1e9, sum = 0;
   for (i64 q = l; q < items; q += G) {
@@ -1811,22 +1816,23 @@ __device__ __forceinline__ void softmax_bwd_seg_body(
     if constexpr (EID_ID) return e0 * h + q;
     else return eid[e0 + q / h] * h + t;
   };
-  if (items <= (i64)G * R) {
-    T yy[R], dd[R];
+  auto in_regs = [&](auto rc) {
+    constexpr int RR = decltype(rc)::value;
+    T yy[RR], dd[RR];
     T g = 0;
     const int n_it = (int)items;
     if constexpr (EID_ID) {   // one base address + immediate offsets r*G
       const T* yp = y + e0 * h + l;
       const T* dp = dy + e0 * h + l;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RR; ++r) {
         const bool ok = l + r * G < n_it;
         yy[r] = ok ? yp[r * G] : (T)0;
         dd[r] = ok ? dp[r * G] : (T)0;
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RR; ++r) {
         const i64 q = l + (i64)r * G;
         yy[r] = 0; dd[r] = 0;
         if (q < items) {
@@ -1837,24 +1843,26 @@ __device__ __forceinline__ void softmax_bwd_seg_body(
       }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) g += dd[r] * yy[r];
+    for (int r = 0; r < RR; ++r) g += dd[r] * yy[r];
 #pragma unroll
     for (int mask = G / 2; mask >= 1; mask >>= 1)
       if (mask >= h) g += __shfl_xor(g, mask, G);
     if constexpr (EID_ID) {
       T* xp = dx + e0 * h + l;
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < RR; ++r)
         if (l + r * G < n_it) xp[r * G] = dd[r] * yy[r] - g * yy[r];
     } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RR; ++r) {
         const i64 q = l + (i64)r * G;
         if (q < items) dx[offs(q)] = dd[r] * yy[r] - g * yy[r];
       }
     }
-    return;
-  }
+  };
+  if (items <= (i64)G * (R / 4)) { in_regs(std::integral_constant<int, R / 4>{}); return; }
+  if (items <= (i64)G * (R / 2)) { in_regs(std::integral_constant<int, R / 2>{}); return; }
+  if (items <= (i64)G * R) { in_regs(std::integral_constant<int, R>{}); return; }
 
   T g = 0;
   for (i64 q = l; q < items; q += G) {
