@@ -11,8 +11,6 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-echo "[refresh] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o stats -- \
     python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err"
@@ -29,12 +27,17 @@ echo "[refresh] pmc l2 done"
 python tools/pmc_summary.py "$(dirname "$(find "$OUT/pmc_$TAG" -name 'l2_counter_collection.csv' | head -1)")" \
     FETCH_SIZE WRITE_SIZE l2 > "$OUT/${TAG}_pmc_summary.json"
 python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 > "$OUT/${TAG}_pmc_traffic.json"
+# the headline line AFTER the counter passes: bench.py quotes roofline.traffic from profiles/pmc_traffic.json when
+# that file was measured on the same kernel sources (copy the new one into profiles/ afterwards)
+cp "$OUT/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json
+python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+echo "[refresh] bench done"
 [ -n "$QUICK" ] && { echo "[refresh] quick: done"; exit 0; }
 # input variants of the headline workload: worst-case locality, signed values
 python bench.py --alpha 0 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_alpha0_bench.json" 2>/dev/null
 python bench.py --values normal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_normal_bench.json" 2>/dev/null
 # the same graph at other row widths / head counts (not BASELINE configs: how far the headline tuning carries)
-for cfg in "128 1" "256 1" "16 4" "32 8"; do
+for cfg in "128 1" "256 1" "16 4" "32 2" "32 8"; do
   set -- $cfg
   python bench.py --graph reddit --d $1 --heads $2 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_h$2_d$1_bench.json" 2>/dev/null
 done
