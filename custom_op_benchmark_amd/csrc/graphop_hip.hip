@@ -890,20 +890,23 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
     // several heads in storage order: float4 items (kernels_fast.h: softmax_vec4_group)
     if (id && pow2(h) && h >= 4 && h <= 64 && aligned16(in0) && aligned16(out) && (!BWD || aligned16(in1)) &&
         kLongSegment * h < 0x7fffffffLL) {
-      const int G = seg_group_width(p->info.n_edges * h / 4 / S, h / 4);
+      const i64 mean_n4 = p->info.n_edges * h / 4 / S;
+      const int G = seg_group_width(mean_n4, h / 4);
+      const bool small_rows = mean_n4 <= 2 * G;     // most rows within 8 float4s per lane: the low-register instantiation
       const int n_long = (int)p->n_long;
       const unsigned nb = blocks_for(S, kFastBlock / G) + (unsigned)n_long;
       const i64 long_len = n_long > 0 ? kLongSegment : (i64)1 << 30;
       prof.kernel = BWD ? "k_softmax_bwd_vec4" : "k_softmax_fwd_vec4";
-#define GO_V4(GW)                                                                                   \
+#define GO_V4R(GW, RM)                                                                              \
   if constexpr (!BWD)                                                                               \
-    hipLaunchKernelGGL((k_softmax_fwd_vec4<GW>), dim3(nb), dim3(kFastBlock), 0, st,                 \
+    hipLaunchKernelGGL((k_softmax_fwd_vec4<GW, (RM ? 8 : kVec4CacheFwd)>), dim3(nb), dim3(kFastBlock), 0, st, \
                        (const i64*)p->seg_chunk, indptr, in0, out, S, (int)h, long_len,             \
                        (const int*)p->long_segs, n_long, (const i64*)p->row, stats);                \
   else                                                                                              \
-    hipLaunchKernelGGL((k_softmax_bwd_vec4<GW>), dim3(nb), dim3(kFastBlock), 0, st,                 \
+    hipLaunchKernelGGL((k_softmax_bwd_vec4<GW, (RM ? 8 : kVec4CacheBwd)>), dim3(nb), dim3(kFastBlock), 0, st, \
                        (const i64*)p->seg_chunk, indptr, in0, in1, out, S, (int)h, long_len,        \
                        (const int*)p->long_segs, n_long);
+#define GO_V4(GW) if (small_rows) { GO_V4R(GW, 1) } else { GO_V4R(GW, 0) }
       switch (G) {
         case 8: GO_V4(8) break;
         case 16: GO_V4(16) break;
@@ -911,6 +914,7 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
         default: GO_V4(64) break;
       }
 #undef GO_V4
+#undef GO_V4R
       GO_LAUNCH_CHECK();
       return GRAPHOP_OK;
     }

@@ -2140,12 +2140,16 @@ __device__ __forceinline__ void softmax_vec4_regs(const float4* __restrict__ p0,
 }
 
 // in0 = x (forward) | y (backward), in1 = dy.  Semantics as softmax_*_seg_body (graphop_kernel.cu:170-230).
-template <int G, bool BWD>
+// RMAX = most float4s per lane the register tiers may hold: the kernel's register count -- and with it how many
+// waves a SIMD holds -- follows the largest tier compiled in.  Graphs of short rows (products-shape: 25 slots
+// x 8 heads = 50 float4s per row) are bound by the chain of dependent loads per row (segment bounds, slot bounds,
+// items), i.e. by resident waves: they take the RMAX = 8 instantiation (longer rows loop).
+template <int G, bool BWD, int RMAX>
 __device__ __forceinline__ void softmax_vec4_group(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ in0,
     const float* __restrict__ in1, float* __restrict__ out, i64 n_seg, int h, i64 long_len, i64 block,
     const i64* __restrict__ row, float* __restrict__ stats) {
-  constexpr int R4 = BWD ? kVec4CacheBwd : kVec4CacheFwd;
+  constexpr int R4 = RMAX;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;                         // group-uniform
@@ -2162,7 +2166,9 @@ __device__ __forceinline__ void softmax_vec4_group(
   float* st_row = (stats && l < hq) ? stats + (row[seg_chunk[s]] * h + 4 * l) * 2 : nullptr;
   if (n4 <= G * 4) { softmax_vec4_regs<G, 4, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
   if (n4 <= G * 8) { softmax_vec4_regs<G, 8, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
-  if (n4 <= G * 16) { softmax_vec4_regs<G, 16, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  if constexpr (R4 >= 16) {
+    if (n4 <= G * 16) { softmax_vec4_regs<G, 16, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
+  }
   if constexpr (R4 > 16) {
     if (n4 <= G * R4) { softmax_vec4_regs<G, R4, BWD>(p0, p1, po, n4, l, hq, st_row); return; }
   }
@@ -2284,7 +2290,7 @@ __device__ __forceinline__ void softmax_vec4_long_regs(const float4* __restrict_
 }
 
 // Rows above long_len slots: one workgroup per row, float4 items, statistics merged through LDS.
-template <bool BWD>
+template <bool BWD, int RMAX>
 __device__ __forceinline__ void softmax_vec4_long(
     const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
     const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ out, int h,
@@ -2298,10 +2304,10 @@ __device__ __forceinline__ void softmax_vec4_long(
   const float4* p0 = reinterpret_cast<const float4*>(in0 + e0 * h);
   const float4* p1 = BWD ? reinterpret_cast<const float4*>(in1 + e0 * h) : nullptr;
   float4* po = reinterpret_cast<float4*>(out + e0 * h);
-  if (n4 <= 16 * kFastBlock) {                    // block-uniform
+  if (n4 <= (RMAX >= 16 ? 16 : 8) * kFastBlock) {  // block-uniform
     float* st_row = (!BWD && stats && tid < hq) ? stats + (row[seg_chunk[s]] * h + 4 * tid) * 2 : nullptr;
-    if (n4 <= 8 * kFastBlock) softmax_vec4_long_regs<8, BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
-    else softmax_vec4_long_regs<16, BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
+    if (RMAX < 16 || n4 <= 8 * kFastBlock) softmax_vec4_long_regs<8, BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
+    else softmax_vec4_long_regs<(RMAX >= 16 ? 16 : 8), BWD>(p0, p1, po, (int)n4, hq, sh_m, sh_s, st_row);
     return;
   }
   constexpr int U = 4;
@@ -2364,7 +2370,7 @@ __device__ __forceinline__ void softmax_vec4_long(
   }
 }
 
-template <int G>
+template <int G, int RMAX>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_vec4(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ x,
     float* __restrict__ y, i64 n_seg, int h, i64 long_len, const int* __restrict__ long_segs, int n_long,
@@ -2372,12 +2378,12 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_vec4(
   __shared__ float4 sh_m[kFastBlock];
   __shared__ float4 sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_vec4_long<false>(long_segs, seg_chunk, indptr, x, nullptr, y, h, sh_m, sh_s, long_len, row, stats);
+    softmax_vec4_long<false, RMAX>(long_segs, seg_chunk, indptr, x, nullptr, y, h, sh_m, sh_s, long_len, row, stats);
   else
-    softmax_vec4_group<G, false>(seg_chunk, indptr, x, nullptr, y, n_seg, h, long_len, (i64)blockIdx.x - n_long, row, stats);
+    softmax_vec4_group<G, false, RMAX>(seg_chunk, indptr, x, nullptr, y, n_seg, h, long_len, (i64)blockIdx.x - n_long, row, stats);
 }
 
-template <int G>
+template <int G, int RMAX>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_vec4(
     const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ y,
     const float* __restrict__ dy, float* __restrict__ dx, i64 n_seg, int h, i64 long_len,
@@ -2385,9 +2391,9 @@ __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_vec4(
   __shared__ float4 sh_m[kFastBlock];
   __shared__ float4 sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_vec4_long<true>(long_segs, seg_chunk, indptr, y, dy, dx, h, sh_m, sh_s, long_len, nullptr, nullptr);
+    softmax_vec4_long<true, RMAX>(long_segs, seg_chunk, indptr, y, dy, dx, h, sh_m, sh_s, long_len, nullptr, nullptr);
   else
-    softmax_vec4_group<G, true>(seg_chunk, indptr, y, dy, dx, n_seg, h, long_len, (i64)blockIdx.x - n_long, nullptr, nullptr);
+    softmax_vec4_group<G, true, RMAX>(seg_chunk, indptr, y, dy, dx, n_seg, h, long_len, (i64)blockIdx.x - n_long, nullptr, nullptr);
 }
 
 // Any h (G need not be a multiple of h): heads in an outer loop, strided reads.

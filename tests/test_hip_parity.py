@@ -555,6 +555,44 @@ def test_softmax_several_heads_float4_items(dev, h):
         close(dx, oracle.sparse_softmax_backward(*a3, yo, ge), rtol=1e-3, atol=1e-6)
 
 
+def test_misaligned_head_tensors_fall_back(dev):
+    """The float4 softmax and the several-heads walk kernel read (E, h) arrays with 16-byte loads; a view that
+    starts 4 bytes into its storage takes the scalar forms instead -- same results, no error."""
+    h, d, n = 8, 32, 600
+    g = random_graph(n, n, 12 * n, seed=91, chunk_size=32, hub=700).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(6)
+    x = torch.randn(g.n_edges, h, device=dev, generator=gen)
+    V = torch.randn(n, h, d, device=dev, generator=gen)
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, device=dev, dtype=t.dtype)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+        return v
+    a3 = (g.row, g.ptr_r, g.eid_r)
+    y = ops.sparse_softmax_forward(*a3, x)
+    y_s = ops.sparse_softmax_forward(*a3, shifted(x))
+    torch.testing.assert_close(y_s, y, rtol=1e-5, atol=1e-7)
+    gy = torch.randn(g.n_edges, h, device=dev, generator=gen)
+    torch.testing.assert_close(ops.sparse_softmax_backward(*a3, shifted(y), shifted(gy)),
+                               ops.sparse_softmax_backward(*a3, y, gy), rtol=1e-5, atol=1e-7)
+    _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 64); _lib.tune("walk_min_bin", 0)
+    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512); _lib.tune("walk_blocks", 8)
+    _lib.clear_plan_cache()
+    try:
+        a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+        _lib.profile_enable(True)
+        o = ops.vector_spmm_forward(*a4, y, V)
+        torch.cuda.synchronize()
+        assert {r.get("kernel") for r in _lib.profile_read().values()} >= {"k_spmm_walk_f32"}
+        o_s = ops.vector_spmm_forward(*a4, shifted(y), V)
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        torch.testing.assert_close(o_s, o, rtol=1e-4, atol=1e-6)
+    finally:
+        _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()
+
+
 def test_scalar_transpose_path_matches(dev, force_sweep):
     """Optional column-major path (off by default): per-slot scalars transposed by a paced scatter
     before the SpMM; must give the same dB / dx as the gather path."""
