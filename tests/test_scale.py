@@ -103,6 +103,66 @@ def test_reddit_scale_fused_equals_unfused(dev):
     torch.testing.assert_close((K.double() * k2.grad.double()).sum(), (Q.double() * q2.grad.double()).sum(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("h,d", [(8, 32), (4, 16)])
+def test_reddit_scale_several_heads(dev, h, d):
+    """The reference's second benchmarked layout (several heads, wrapper.py:306-386) at the Reddit shape and the
+    default geometry: walk SpMM with per-head weight rings, staged SDDMM with heads of d / 4 lanes, float4 softmax.
+    Checked three ways: against the chunk drivers (another kernel family, knob sweep = 0) on the same inputs;
+    head 3 against a one-head run on that head's slices (other instantiations again); adjoint identities that tie
+    forward and backward passes together."""
+    N, E = graphs.SHAPES["reddit"]
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    Q, K, V, dO = (torch.randn(N, h, d, device=dev, generator=gen) / 4 for _ in range(4))
+    a4, a8, a3 = (g.row, g.ptr_r, g.eid_r, g.indices_r), g.csr_args(), (g.row, g.ptr_r, g.eid_r)
+
+    def step():
+        s = ops.maskedmm_csr_forward(*a4, Q, K)
+        a = ops.sparse_softmax_forward(*a3, s)
+        o = ops.vector_spmm_forward(*a4, a, V)
+        da, dV = ops.vector_spmm_backward(*a8, a, dO, V)
+        ds = ops.sparse_softmax_backward(*a3, a, da)
+        dQ, dK = ops.maskedmm_csr_backward(*a8, Q, K, ds)
+        return dict(s=s, a=a, o=o, da=da, dV=dV, ds=ds, dQ=dQ, dK=dK)
+
+    _lib.profile_enable(True)
+    got = step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["sddmm_fwd"]["kernel"] == "k_sddmm_wown_staged_f32" and prof["spmm_bwd_dedata"]["kernel"] == "k_sddmm_wown_staged_f32", prof
+    for p in ("spmm_fwd", "spmm_bwd_dx", "sddmm_bwd_dA", "sddmm_bwd_dB"):
+        assert prof[p]["kernel"] == "k_spmm_walk_f32", (p, prof[p])
+    assert prof["softmax_fwd"]["kernel"] == "k_softmax_fwd_vec4" and prof["softmax_bwd"]["kernel"] == "k_softmax_bwd_vec4", prof
+    # adjoint identities (fp64 dot products of fp32 results)
+    lhs = _dot(got["o"], dO)
+    torch.testing.assert_close(_dot(got["a"], got["da"]), lhs, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(_dot(V, got["dV"]), lhs, rtol=1e-5, atol=1e-6)
+    ref = _dot(got["s"], got["ds"])
+    torch.testing.assert_close(_dot(Q, got["dQ"]), ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(_dot(K, got["dK"]), ref, rtol=1e-4, atol=1e-5)
+    # head 3 alone through the one-head kernels
+    q3, k3, v3, g3 = (x[:, 3, :].contiguous() for x in (Q, K, V, dO))
+    s3 = ops.maskedmm_csr_forward(*a4, q3, k3)
+    torch.testing.assert_close(got["s"][:, 3], s3, rtol=1e-5, atol=1e-6)
+    a_3 = ops.sparse_softmax_forward(*a3, s3)
+    torch.testing.assert_close(got["a"][:, 3], a_3, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(got["o"][:, 3, :], ops.vector_spmm_forward(*a4, a_3, v3), rtol=2e-4, atol=2e-5)
+    del s3, a_3, q3, k3, v3, g3
+    # the chunk drivers on the same inputs
+    _lib.tune("sweep", 0); _lib.tune("walk", 0)
+    try:
+        want = step()
+        torch.cuda.synchronize()
+    finally:
+        _lib.tune_reset()
+    tol = dict(rtol=2e-4, atol=2e-5)
+    for k in ("s", "a", "o", "da", "dV", "dQ", "dK"):
+        torch.testing.assert_close(got[k], want[k], **tol)
+    del got, want
+    ops.release(g)
+
+
 def test_products_scale_properties(dev):
     """BASELINE config 3 (h = 8, d = 128): ones -> d per head and degree; linearity; adjointness ties
     the forward and both backward passes of every gather op together; rows of the softmax sum to 1."""
