@@ -108,7 +108,8 @@ def test_walk_rows_longer_than_many_bins(dev, force_walk):
         close(got[k], want[k])
 
 
-def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk):
+@pytest.mark.parametrize("h,d", [(1, 64), (4, 16)])
+def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk, h, d):
     """graphop.prepare builds the walk layouts too: the step afterwards allocates nothing, so it captures
     into a HIP graph, and the replay (walk kernels with their pacer counters zeroed inside the graph)
     reproduces the eager result."""
@@ -116,12 +117,13 @@ def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk):
     _lib.tune("walk_blocks", 16)
     g = random_graph(1500, 1500, 15000, seed=13, chunk_size=32, hub=900).to(dev)
     gen = torch.Generator(device=dev).manual_seed(4)
-    Q, K, V, dO = (torch.randn(1500, 64, device=dev, generator=gen) / 8 for _ in range(4))
-    ops.prepare(g, h=1, d=64, fused=False)
+    shape = (1500, 64) if h == 1 else (1500, h, d)
+    Q, K, V, dO = (torch.randn(shape, device=dev, generator=gen) / 8 for _ in range(4))
+    ops.prepare(g, h=h, d=d, fused=False)
     held = _lib.plan_memory_bytes()
     want = hip_step(g, Q, K, V, dO)
     assert _lib.plan_memory_bytes() == held            # the eager step built nothing after prepare
-    assert WALK_KERNELS <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
+    assert (WALK_KERNELS if h == 1 else {"k_spmm_walk_f32"}) <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
     a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
     s = ops.maskedmm_csr_forward(*a4, Q, K)
     a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
