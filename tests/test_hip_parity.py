@@ -632,6 +632,13 @@ def test_fuzz_shapes_and_paths(dev, seed):
         _lib.tune("sweep_prefetch", int(rng.choice([0, 1]))); _lib.tune("transpose_scalars", int(rng.choice([0, 1])))
         _lib.tune("sweep_mode", int(rng.choice([0, 1])))
         _lib.tune("staged_ids", int(rng.choice([0, 7, 7]))); _lib.tune("sweep_k", int(rng.choice([0, 0, 1, 2, 4, 8])))
+        if rng.rand() < 0.6:     # walk drivers too (one head and several), tiny windows and grids
+            _lib.tune("walk", int(rng.choice([6, 7]))); _lib.tune("walk_min_bin", 0)
+            _lib.tune("walk_window_kb", int(rng.choice([2, 8, 32]))); _lib.tune("walk_window_kb_col", int(rng.choice([2, 8, 32])))
+            _lib.tune("walk_blocks", int(rng.choice([0, 8, 24]))); _lib.tune("walk_drift", int(rng.choice([0, 1, 2, 3])))
+            _lib.tune("walk_steps", int(rng.choice([1, 2, 3]))); _lib.tune("max_windows", 512)
+        else:
+            _lib.tune("walk", 0)
     _lib.clear_plan_cache()
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
@@ -645,10 +652,7 @@ def test_fuzz_shapes_and_paths(dev, seed):
         for k in ("s", "a", "o", "dQ", "dK", "dV"):
             close(got[k], want[k], rtol=2e-4, atol=2e-5)
     finally:
-        for key, val in (("sweep_min_kb", 4608), ("sweep_min_granule", 4), ("max_windows", 128), ("window_kb", 4096),
-                         ("vrow_t", 0), ("sweep_drift", 2), ("sweep_bpc", 3), ("sweep_prefetch", 0),
-                         ("transpose_scalars", 0), ("sweep_mode", 1), ("staged_ids", 7), ("sweep_k", 0)):
-            _lib.tune(key, val)
+        _lib.tune_reset()
         _lib.clear_plan_cache()
 
 
@@ -765,6 +769,5 @@ def test_step_replays_from_a_captured_hip_graph(dev, shape):
             for x, k in zip(got, ("s", "a", "o", "dQ", "dK", "dV")):
                 torch.testing.assert_close(x, ref[k], rtol=1e-4, atol=1e-5)
     finally:
-        if forced:
-            _lib.tune("sweep_min_kb", 4608); _lib.tune("window_kb", 4096); _lib.tune("vrow_t", 0); _lib.tune("sweep_min_granule", 4)
+        _lib.tune_reset()
         _lib.clear_plan_cache()
