@@ -126,8 +126,16 @@ _live_blocks = {}
 
 
 def _alloc_cb(nbytes, device, stream):
+    # The block is allocated ON the stream the library names (torch's caching allocator recycles memory in
+    # allocation-stream order), and a block is only handed back once the device is idle (below): a plan may have
+    # been used from any stream since, and the hipFree this hook replaces synchronised the device as well.
     try:
-        t = torch.empty(max(1, int(nbytes)), dtype=torch.uint8, device=torch.device("cuda", device))
+        dev = torch.device("cuda", device)
+        if stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                t = torch.empty(max(1, int(nbytes)), dtype=torch.uint8, device=dev)
+        else:
+            t = torch.empty(max(1, int(nbytes)), dtype=torch.uint8, device=dev)
     except RuntimeError:        # out of memory: the library reports it
         return None
     _live_blocks[t.data_ptr()] = t
@@ -135,7 +143,13 @@ def _alloc_cb(nbytes, device, stream):
 
 
 def _free_cb(p):
-    _live_blocks.pop(p, None)
+    t = _live_blocks.pop(p, None)
+    if t is not None:
+        try:
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(t.device)
+        except Exception:       # (interpreter shutdown, device lost: drop the block regardless)
+            pass
 
 
 _ALLOC_CB, _FREE_CB = ALLOC_FN(_alloc_cb), FREE_FN(_free_cb)
