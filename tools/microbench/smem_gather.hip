@@ -11,7 +11,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <bool SCALAR>
+template <int MODE>   // 0 plain vector load, 1 nontemporal, 2 agent-scope relaxed atomic load (sc1), 3 scalar cache
 __global__ __launch_bounds__(1024) void k_gather(const float* __restrict__ w, const int* __restrict__ idx, float* __restrict__ out,
                                                  long long per_wave) {
   const int lane = threadIdx.x & 63;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(1024) void k_gather(const float* __restrict__ w, co
   float acc = 0.f;
   for (long long j = 0; j < per_wave; j += 64) {
     const int e = my[j + lane];
-    if constexpr (SCALAR) {
+    if constexpr (MODE == 3) {
       float v = 0.f;
 #pragma unroll
       for (int i0 = 0; i0 < 64; i0 += 32) {         // 32 scalar loads in flight per wave, one wait
@@ -38,6 +38,10 @@ __global__ __launch_bounds__(1024) void k_gather(const float* __restrict__ w, co
         }
       }
       acc += v;
+    } else if constexpr (MODE == 1) {
+      acc += __builtin_nontemporal_load(w + e);
+    } else if constexpr (MODE == 2) {
+      acc += __hip_atomic_load(w + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       acc += w[e];
     }
@@ -65,17 +69,21 @@ int main() {
     int* idx; CK(hipMalloc(&idx, h.size() * 4)); CK(hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     float* out; CK(hipMalloc(&out, waves * 64 * 4));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int scalar = 0; scalar < 2; ++scalar) {
+    for (int mode = 0; mode < 4; ++mode) {
       float best = 1e9f;
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
-        if (scalar) hipLaunchKernelGGL(k_gather<true>, dim3(cus), dim3(64 * waves_per_cu), 0, 0, w, idx, out, per_wave);
-        else hipLaunchKernelGGL(k_gather<false>, dim3(cus), dim3(64 * waves_per_cu), 0, 0, w, idx, out, per_wave);
+        const dim3 g(cus), t(64 * waves_per_cu);
+        if (mode == 0) hipLaunchKernelGGL(k_gather<0>, g, t, 0, 0, w, idx, out, per_wave);
+        else if (mode == 1) hipLaunchKernelGGL(k_gather<1>, g, t, 0, 0, w, idx, out, per_wave);
+        else if (mode == 2) hipLaunchKernelGGL(k_gather<2>, g, t, 0, 0, w, idx, out, per_wave);
+        else hipLaunchKernelGGL(k_gather<3>, g, t, 0, 0, w, idx, out, per_wave);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         best = ms < best ? ms : best;
       }
-      printf("waves/CU %2d  %s gather of %lld scalars: %.3f ms  (%.1f G scalars/s)\n", waves_per_cu, scalar ? "scalar-cache" : "vector      ",
+      const char* names[4] = {"vector plain ", "vector nt    ", "vector sc1   ", "scalar cache "};
+      printf("waves/CU %2d  %s gather of %lld scalars: %.3f ms  (%.1f G scalars/s)\n", waves_per_cu, names[mode],
              waves * per_wave, best, waves * per_wave / best / 1e6);
     }
     CK(hipFree(idx)); CK(hipFree(out));
