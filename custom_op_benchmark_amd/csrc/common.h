@@ -157,6 +157,7 @@ struct graphop_plan {
   const int64_t* eid;
   const int64_t* indices;
   int64_t* seg_chunk;      // [n_segments + 1] first chunk of each segment, then n_chunks (owned)
+  int64_t* seg_eptr;       // [n_segments + 1] first slot of each segment, then the end of the last (owned, optional; row_owned plans)
   int32_t* idx32;          // [n_edges] (owned, optional)
   int32_t* eid32;          // [n_edges] (owned, optional; NULL when eid is the identity)
   int32_t* long_segs;      // [n_long] segments longer than kLongSegment slots (owned)

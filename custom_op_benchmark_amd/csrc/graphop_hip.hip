@@ -126,6 +126,7 @@ void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_inverse(graphop_plan*, hipStream_t);
 int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**);
+int plan_build_seg_eptr(graphop_plan*, hipStream_t);
 int* plan_take_walk_sync(graphop_plan*, const Walk*);
 
 Tuning& tuning_mut() {
@@ -900,11 +901,11 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
 #define GO_V4R(GW, RM)                                                                              \
   if constexpr (!BWD)                                                                               \
     hipLaunchKernelGGL((k_softmax_fwd_vec4<GW, (RM ? 8 : kVec4CacheFwd)>), dim3(nb), dim3(kFastBlock), 0, st, \
-                       (const i64*)p->seg_chunk, indptr, in0, out, S, (int)h, long_len,             \
+                       (const i64*)p->seg_chunk, indptr, (const i64*)p->seg_eptr, in0, out, S, (int)h, long_len,             \
                        (const int*)p->long_segs, n_long, (const i64*)p->row, stats);                \
   else                                                                                              \
     hipLaunchKernelGGL((k_softmax_bwd_vec4<GW, (RM ? 8 : kVec4CacheBwd)>), dim3(nb), dim3(kFastBlock), 0, st, \
-                       (const i64*)p->seg_chunk, indptr, in0, in1, out, S, (int)h, long_len,        \
+                       (const i64*)p->seg_chunk, indptr, (const i64*)p->seg_eptr, in0, in1, out, S, (int)h, long_len,        \
                        (const int*)p->long_segs, n_long);
 #define GO_V4(GW) if (small_rows) { GO_V4R(GW, 1) } else { GO_V4R(GW, 0) }
       switch (G) {
@@ -927,11 +928,11 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
 #define GO_SEG(GW, ID)                                                                           \
   if constexpr (!BWD)                                                                            \
     hipLaunchKernelGGL((k_softmax_fwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
-                       (const i64*)p->seg_chunk, indptr, eid, in0, out, S, (int)h, long_len,     \
+                       (const i64*)p->seg_chunk, indptr, (const i64*)p->seg_eptr, eid, in0, out, S, (int)h, long_len,     \
                        (const int*)p->long_segs, n_long, (const i64*)p->row, stats);             \
   else                                                                                           \
     hipLaunchKernelGGL((k_softmax_bwd_seg<T, GW, ID>), dim3(nb), dim3(kFastBlock), 0, st,        \
-                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, (int)h, long_len, \
+                       (const i64*)p->seg_chunk, indptr, (const i64*)p->seg_eptr, eid, in0, in1, out, S, (int)h, long_len, \
                        (const int*)p->long_segs, n_long);
 #define GO_SEG_ID(GW) if (id) { GO_SEG(GW, true) } else { GO_SEG(GW, false) }
     switch (G) {
@@ -945,7 +946,7 @@ int launch_softmax_seg(const graphop_plan* p, const i64* indptr, const i64* eid,
   } else {
     const unsigned nb = blocks_for(S, kFastBlock / kWave);
     hipLaunchKernelGGL((k_softmax_seg_anyh<T, BWD>), dim3(nb), dim3(kFastBlock), 0, st,
-                       (const i64*)p->seg_chunk, indptr, eid, in0, in1, out, S, h, (const i64*)p->row,
+                       (const i64*)p->seg_chunk, indptr, (const i64*)p->seg_eptr, eid, in0, in1, out, S, h, (const i64*)p->row,
                        BWD ? (T*)nullptr : stats);
   }
   GO_LAUNCH_CHECK();
@@ -1197,7 +1198,8 @@ int graphop_plan_create(const int64_t* row, const int64_t* indptr, const int64_t
   p->info.n_edges = n_edges;
   (void)hipGetDevice(&p->device);
   plan_init_sweeps(p);
-  const int rc = plan_build(p, n_index_bound, (hipStream_t)stream, tuning().dense_detect_min_fill);
+  int rc = plan_build(p, n_index_bound, (hipStream_t)stream, tuning().dense_detect_min_fill);
+  if (rc == GRAPHOP_OK) rc = plan_build_seg_eptr(p, (hipStream_t)stream);
   if (rc != GRAPHOP_OK) {
     graphop_plan_destroy(p);
     return rc;
@@ -1307,8 +1309,9 @@ int graphop_plan_import(const int64_t* row, const int64_t* indptr, const int64_t
   p->info = *info;
   (void)hipGetDevice(&p->device);
   plan_init_sweeps(p);
-  const int rc = plan_import_arrays(p, (const i64*)seg_chunk, idx32, eid32, long_segs, n_long, blk_seg, seg_e0,
-                                    seg_row, (hipStream_t)stream);
+  int rc = plan_import_arrays(p, (const i64*)seg_chunk, idx32, eid32, long_segs, n_long, blk_seg, seg_e0,
+                              seg_row, (hipStream_t)stream);
+  if (rc == GRAPHOP_OK) rc = plan_build_seg_eptr(p, (hipStream_t)stream);
   if (rc != GRAPHOP_OK) { graphop_plan_destroy(p); return rc; }
   *plan_out = p;
   return GRAPHOP_OK;
@@ -1350,6 +1353,7 @@ void graphop_plan_destroy(graphop_plan_t* plan) {
   if (!plan) return;
   plan_free_sweeps(plan);
   if (plan->seg_chunk) go_free(plan->seg_chunk);
+  if (plan->seg_eptr) go_free(plan->seg_eptr);
   if (plan->idx32) go_free(plan->idx32);
   if (plan->eid32) go_free(plan->eid32);
   if (plan->long_segs) go_free(plan->long_segs);

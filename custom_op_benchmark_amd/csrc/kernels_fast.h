@@ -1690,6 +1690,13 @@ __global__ __launch_bounds__(kFastBlock) void k_scatter_scalars_sweep(
 // Semantics: graphop_kernel.cu:170-202 (m starts at -1e9, :428).
 // items per lane kept in registers (rows up to G*R items are read once).  Measured on Reddit-shape
 // (mean row 492, 23 % of the rows above 512): forward best at 16, backward at 32.
+// First slot of segment s: from the plan's per-segment array when it has one (one dependent load less in front of
+// every row: short rows are bound by that chain), else through the chunk arrays.
+__device__ __forceinline__ i64 seg_first(const i64* __restrict__ seg_eptr, const i64* __restrict__ seg_chunk,
+                                         const i64* __restrict__ indptr, i64 s) {
+  return seg_eptr ? seg_eptr[s] : indptr[seg_chunk[s]];
+}
+
 constexpr int kSoftmaxCacheFwd = 16;
 constexpr int kSoftmaxCacheBwd = 32;
 
@@ -1701,15 +1708,15 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 // Segments longer than `long_len` slots are left to k_softmax_*_long (one workgroup per row).
 template <typename T, int G, bool EID_ID>
 __device__ __forceinline__ void softmax_fwd_seg_body(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
     i64 long_len, i64 block, const i64* __restrict__ row, T* __restrict__ stats) {
   constexpr int R = kSoftmaxCacheFwd;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
-  const i64 e0 = indptr[seg_chunk[s]];
-  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s);
+  const i64 len = seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0;
   if (len > long_len) return;
   const i64 items = len * h;
   const int t = l % h;
@@ -1797,7 +1804,7 @@ __device__ __forceinline__ void softmax_fwd_seg_body(
 // Backward: g = sum dy*y over the row; dx = dy*y - g*y   (graphop_kernel.cu:208-230)
 template <typename T, int G, bool EID_ID>
 __device__ __forceinline__ void softmax_bwd_seg_body(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
     T* __restrict__ dx, i64 n_seg, int h, i64 long_len, i64 block) {
   // gathered through eid every cached item carries its own 64-bit offset: 8 per lane fit the
@@ -1806,8 +1813,8 @@ __device__ __forceinline__ void softmax_bwd_seg_body(
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;
-  const i64 e0 = indptr[seg_chunk[s]];
-  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s);
+  const i64 len = seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0;
   if (len > long_len) return;
   const i64 items = len * h;
   const int t = l % h;
@@ -1912,14 +1919,14 @@ __device__ __forceinline__ void block_merge(T& m, T& sum, T* sh_m, T* sh_s, int 
 template <typename T, bool BWD, bool EID_ID>
 __device__ __forceinline__ void softmax_long_body(
     const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk,
-    const i64* __restrict__ indptr, const i64* __restrict__ eid, const T* __restrict__ in0,
+    const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr, const i64* __restrict__ eid, const T* __restrict__ in0,
     const T* __restrict__ in1, T* __restrict__ out, int h, T* sh_m, T* sh_s, i64 long_len,
     const i64* __restrict__ row = nullptr, T* __restrict__ stats = nullptr) {
   constexpr int RB = kBlockCache;
   const i64 s = long_segs[blockIdx.x];
-  const i64 e0 = indptr[seg_chunk[s]];
-  if (indptr[seg_chunk[s + 1]] - e0 <= long_len) return;   // block-uniform: the per-row groups take it
-  const i64 items = (indptr[seg_chunk[s + 1]] - e0) * h;
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s);
+  if (seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0 <= long_len) return;   // block-uniform: the per-row groups take it
+  const i64 items = (seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0) * h;
   const int tid = threadIdx.x, t = tid % h;
   auto offs = [&](i64 q) -> i64 {   // 256 % h == 0, so q % h == t for every q of this thread
     if constexpr (EID_ID) return e0 * h + q;
@@ -2026,32 +2033,32 @@ __device__ __forceinline__ void softmax_long_body(
 // loops overlap the bulk), the rest take kFastBlock/G ordinary row segments each.
 template <typename T, int G, bool EID_ID>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_seg(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const i64* __restrict__ eid, const T* __restrict__ x, T* __restrict__ y, i64 n_seg, int h,
     i64 long_len, const int* __restrict__ long_segs, int n_long, const i64* __restrict__ row,
     T* __restrict__ stats) {
   __shared__ T sh_m[kFastBlock];
   __shared__ T sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_long_body<T, false, EID_ID>(long_segs, seg_chunk, indptr, eid, x, (const T*)nullptr, y, h,
+    softmax_long_body<T, false, EID_ID>(long_segs, seg_chunk, indptr, seg_eptr, eid, x, (const T*)nullptr, y, h,
                                         sh_m, sh_s, long_len, row, stats);
   else
-    softmax_fwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, x, y, n_seg, h, long_len,
+    softmax_fwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, seg_eptr, eid, x, y, n_seg, h, long_len,
                                        (i64)blockIdx.x - n_long, row, stats);
 }
 
 template <typename T, int G, bool EID_ID>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_seg(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const i64* __restrict__ eid, const T* __restrict__ y, const T* __restrict__ dy,
     T* __restrict__ dx, i64 n_seg, int h, i64 long_len, const int* __restrict__ long_segs,
     int n_long) {
   __shared__ T sh_m[kFastBlock];
   __shared__ T sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_long_body<T, true, EID_ID>(long_segs, seg_chunk, indptr, eid, y, dy, dx, h, sh_m, sh_s, long_len);
+    softmax_long_body<T, true, EID_ID>(long_segs, seg_chunk, indptr, seg_eptr, eid, y, dy, dx, h, sh_m, sh_s, long_len);
   else
-    softmax_bwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, eid, y, dy, dx, n_seg, h, long_len,
+    softmax_bwd_seg_body<T, G, EID_ID>(seg_chunk, indptr, seg_eptr, eid, y, dy, dx, n_seg, h, long_len,
                                        (i64)blockIdx.x - n_long);
 }
 
@@ -2146,15 +2153,15 @@ __device__ __forceinline__ void softmax_vec4_regs(const float4* __restrict__ p0,
 // items), i.e. by resident waves: they take the RMAX = 8 instantiation (longer rows loop).
 template <int G, bool BWD, int RMAX>
 __device__ __forceinline__ void softmax_vec4_group(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ in0,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr, const float* __restrict__ in0,
     const float* __restrict__ in1, float* __restrict__ out, i64 n_seg, int h, i64 long_len, i64 block,
     const i64* __restrict__ row, float* __restrict__ stats) {
   constexpr int R4 = RMAX;
   const int l = threadIdx.x % G;
   const i64 s = block * (kFastBlock / G) + threadIdx.x / G;
   if (s >= n_seg) return;                         // group-uniform
-  const i64 e0 = indptr[seg_chunk[s]];
-  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s);
+  const i64 len = seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0;
   if (len > long_len) return;
   const int n4 = (int)(len * h / 4);
   const int hq = h / 4;                           // lanes hq apart hold the same heads
@@ -2292,12 +2299,12 @@ __device__ __forceinline__ void softmax_vec4_long_regs(const float4* __restrict_
 // Rows above long_len slots: one workgroup per row, float4 items, statistics merged through LDS.
 template <bool BWD, int RMAX>
 __device__ __forceinline__ void softmax_vec4_long(
-    const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const int* __restrict__ long_segs, const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ out, int h,
     float4* sh_m, float4* sh_s, i64 long_len, const i64* __restrict__ row, float* __restrict__ stats) {
   const i64 s = long_segs[blockIdx.x];
-  const i64 e0 = indptr[seg_chunk[s]];
-  const i64 len = indptr[seg_chunk[s + 1]] - e0;
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s);
+  const i64 len = seg_first(seg_eptr, seg_chunk, indptr, s + 1) - e0;
   if (len <= long_len) return;                    // block-uniform: the per-row groups take it
   const i64 n4 = len * h / 4;
   const int tid = threadIdx.x, hq = h / 4;
@@ -2372,41 +2379,41 @@ __device__ __forceinline__ void softmax_vec4_long(
 
 template <int G, int RMAX>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_fwd_vec4(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ x,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr, const float* __restrict__ x,
     float* __restrict__ y, i64 n_seg, int h, i64 long_len, const int* __restrict__ long_segs, int n_long,
     const i64* __restrict__ row, float* __restrict__ stats) {
   __shared__ float4 sh_m[kFastBlock];
   __shared__ float4 sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_vec4_long<false, RMAX>(long_segs, seg_chunk, indptr, x, nullptr, y, h, sh_m, sh_s, long_len, row, stats);
+    softmax_vec4_long<false, RMAX>(long_segs, seg_chunk, indptr, seg_eptr, x, nullptr, y, h, sh_m, sh_s, long_len, row, stats);
   else
-    softmax_vec4_group<G, false, RMAX>(seg_chunk, indptr, x, nullptr, y, n_seg, h, long_len, (i64)blockIdx.x - n_long, row, stats);
+    softmax_vec4_group<G, false, RMAX>(seg_chunk, indptr, seg_eptr, x, nullptr, y, n_seg, h, long_len, (i64)blockIdx.x - n_long, row, stats);
 }
 
 template <int G, int RMAX>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_bwd_vec4(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const float* __restrict__ y,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr, const float* __restrict__ y,
     const float* __restrict__ dy, float* __restrict__ dx, i64 n_seg, int h, i64 long_len,
     const int* __restrict__ long_segs, int n_long) {
   __shared__ float4 sh_m[kFastBlock];
   __shared__ float4 sh_s[kFastBlock];
   if ((int)blockIdx.x < n_long)
-    softmax_vec4_long<true, RMAX>(long_segs, seg_chunk, indptr, y, dy, dx, h, sh_m, sh_s, long_len, nullptr, nullptr);
+    softmax_vec4_long<true, RMAX>(long_segs, seg_chunk, indptr, seg_eptr, y, dy, dx, h, sh_m, sh_s, long_len, nullptr, nullptr);
   else
-    softmax_vec4_group<G, true, RMAX>(seg_chunk, indptr, y, dy, dx, n_seg, h, long_len, (i64)blockIdx.x - n_long, nullptr, nullptr);
+    softmax_vec4_group<G, true, RMAX>(seg_chunk, indptr, seg_eptr, y, dy, dx, n_seg, h, long_len, (i64)blockIdx.x - n_long, nullptr, nullptr);
 }
 
 // Any h (G need not be a multiple of h): heads in an outer loop, strided reads.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(kFastBlock) void k_softmax_seg_anyh(
-    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr,
+    const i64* __restrict__ seg_chunk, const i64* __restrict__ indptr, const i64* __restrict__ seg_eptr,
     const i64* __restrict__ eid, const T* __restrict__ in0 /* x | y */,
     const T* __restrict__ in1 /* - | dy */, T* __restrict__ out, i64 n_seg, i64 h,
     const i64* __restrict__ row = nullptr, T* __restrict__ stats = nullptr) {
   const int lane = threadIdx.x & 63;
   const i64 s = (i64)blockIdx.x * (kFastBlock / kWave) + (threadIdx.x >> 6);
   if (s >= n_seg) return;
-  const i64 e0 = indptr[seg_chunk[s]], e1 = indptr[seg_chunk[s + 1]];
+  const i64 e0 = seg_first(seg_eptr, seg_chunk, indptr, s), e1 = seg_first(seg_eptr, seg_chunk, indptr, s + 1);
   for (i64 t = 0; t < h; ++t) {
     if constexpr (!BWD) {
       T m = (T)-1e9;

@@ -719,6 +719,24 @@ int plan_detect_blocks(graphop_plan* p, hipStream_t st, int min_fill) {
   return GRAPHOP_OK;
 }
 
+// Per-segment first slots for the row-segment softmax kernels (optional: they read the chunk arrays without it).
+int plan_build_seg_eptr(graphop_plan* p, hipStream_t st) {
+  const i64 S = p->info.n_segments;
+  if (p->seg_eptr || !p->info.row_owned || !p->seg_chunk || !p->indptr || S <= 0) return GRAPHOP_OK;
+  if (go_malloc((void**)&p->seg_eptr, sizeof(i64) * (size_t)(S + 1), st) != hipSuccess) {
+    p->seg_eptr = nullptr;
+    (void)hipGetLastError();
+    return GRAPHOP_OK;
+  }
+  hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
+                     (const i64*)p->seg_chunk, (const i64*)p->indptr, S, (i64*)p->seg_eptr);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    go_free(p->seg_eptr); p->seg_eptr = nullptr;
+    return GRAPHOP_ERR_HIP;
+  }
+  return GRAPHOP_OK;
+}
+
 // Build (or fetch) the window-sweep structure for W windows of win_cols ids and vrows of <= T slots.
 int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, const Sweep** out) {
   auto* mu = (std::mutex*)p->sweep_mu;
