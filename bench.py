@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+HBM_COPY_GBS = 6290.0   # measured device copy rate (MI355X_MICROARCH.md, chip level): informative only
 # random whole-row gathers of a table far beyond the Infinity Cache, each row fetched once
 # (MI355X_MICROARCH.md, "Indexed rows": 5.5-5.8 TB/s for 1-2 KB rows)
 HBM_RANDOM_ROW_GBS = 5700.0
@@ -417,12 +418,16 @@ def main():
         except (ValueError, KeyError):
             pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # informative: against the 6.29 TB/s a device-wide copy reaches on this part
+                "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": dom_kernel, "launches_per_step": dom["launches"],
                 "alg_bytes_per_launch": int(dom["bytes"] / max(1, dom["launches"])),
                 "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 4),
                 "step": {"alg_bytes": int(alg_step), "alg_GBps": round(alg_step / 1e6 / ms_per_step, 1),
                          "frac": round(alg_step / 1e6 / ms_per_step / HBM_PEAK_GBS, 4),
+                         "frac_of_copy_rate": round(alg_step / 1e6 / ms_per_step / HBM_COPY_GBS, 4),
                          "frac_at_median_step": round(alg_step / 1e6 / statistics.median(step_ms) / HBM_PEAK_GBS, 4),
                          "kernel_ms_sum": round(sum(p["ms"] for p in passes.values()) +
                                                 sum(o["ms_per_step"] for o in other.values()), 3)},
