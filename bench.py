@@ -162,6 +162,11 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal: build rank 0's shard of a WORLD-way partition and time its "
                          "local compute (exchanges replaced by local copies of the right sizes); timing only")
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="single GPU: run the sharded step through the REAL collective path -- a one-rank nccl (= RCCL) "
+                         "process group, all_to_all_single with async handles and split-size views, no world == 1 short-cut -- "
+                         "with the destinations drawn from the global distribution (--cut) fetched through the exchange as a "
+                         "self-halo; use with --graph papers100m / rmat25")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the step once into a HIP graph and time its replays (single GPU; for the "
                          "launch-bound small shapes -- the headline line is measured with eager API calls)")
@@ -189,6 +194,13 @@ def main():
     _lib.lib()  # fail loudly now if the extension is missing
 
     import torch.distributed as dist
+    if args.rccl_self:
+        if world > 1 or args.emulate_world > 1:
+            raise SystemExit("--rccl-self is the one-rank rehearsal of the RCCL path (no torchrun, no --emulate-world)")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("GRAPHOP_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a GPU
@@ -201,7 +213,7 @@ def main():
         if dist.get_backend() != backend:
             raise SystemExit("asked for backend %s, got %s" % (backend, dist.get_backend()))
 
-    sharded = world > 1 or args.emulate_world > 1
+    sharded = world > 1 or args.emulate_world > 1 or args.rccl_self
     n_parts = world if world > 1 else max(1, args.emulate_world)
     name = args.graph
     if name == "auto":
@@ -223,12 +235,18 @@ def main():
     gdesc = "Chung-Lu(alpha=%.2f)" % args.alpha
     if sharded:
         from custom_op_benchmark_amd import dist as gdist
-        kw = dict(chunk_size=args.chunk_size, timing_only=(world == 1))
+        kw = dict(chunk_size=args.chunk_size, timing_only=(world == 1 and not args.rccl_self))
+        if args.rccl_self:
+            kw["force_collectives"] = True
+        if name == "rmat25" and args.rccl_self:
+            raise SystemExit("--rccl-self builds its self-halo from the Chung-Lu generator's global draws: use --graph papers100m")
         if name == "rmat25":
             runner = gdist.ShardedAttention.synthetic_rmat(25 - 3 + (n_parts - 1).bit_length(), E, n_parts,
                                                            rank, dev, seed=args.seed, **kw)
             gdesc = "R-MAT(0.57,0.19,0.19,0.05) scale %d, equal node ranges" % (25 - 3 + (n_parts - 1).bit_length())
         else:
+            if args.rccl_self:
+                kw["self_halo"] = True
             runner = gdist.ShardedAttention.synthetic(N, E, n_parts, rank, dev, alpha=args.alpha, seed=args.seed,
                                                       cut=cut, **kw)
             gdesc += ", %.0f%% of a rank's edges drawn from the global node distribution" % (100 * cut)
@@ -328,6 +346,7 @@ def main():
         evs[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    _lib.check_errors()    # (device already synchronised) a walk kernel whose hand-over timed out: no number is reported
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if world > 1:
         cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -384,6 +403,29 @@ def main():
 
     pb = pass_bytes(g.n_edges, n_rows, n_cols, h, d, g.n_row_chunks, g.n_col_chunks)
     alg_step = sum(pb.values())
+    # hardware-counter traffic per kernel family (profiles/pmc_traffic.json), quoted only for the kernel sources it
+    # was collected on: next to every ALGORITHMIC fraction (API dtypes: int64 ids, every operand once) the line
+    # carries what the kernel really moved beyond L2 -- the plans read 4-byte id mirrors and skip an identity
+    # eid altogether, so an algorithmic fraction can exceed what the memory system delivered (softmax: 1.89 GB
+    # algorithmic against 1.00 GB moved)
+    sha = kernels_sha()
+    moved_by_kernel, moved_note = {}, "no profiles/pmc_traffic.json for this workload"
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") != "%s_h%d_d%d" % (name, h, d):
+                moved_note = "profiles/pmc_traffic.json is for workload %s" % tj.get("workload")
+            elif tj.get("kernels_sha") != sha:
+                moved_note = ("profiles/pmc_traffic.json was collected on other kernel sources (sha %s, now %s): not quoted"
+                              % (tj.get("kernels_sha"), sha))
+            else:
+                moved_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items()}
+                moved_note = ("NOT measured in this run: rocprofv3 --pmc passes of this command on the same kernel sources "
+                              "(kernels_sha %s), profiles/pmc_traffic.json; per kernel family (row- and column-major "
+                              "launches of one instantiation are averaged); %s" % (sha, tj.get("note", "")))
+        except (ValueError, KeyError):
+            moved_note = "profiles/pmc_traffic.json unreadable"
     passes = {}
     kern = {}
     for tag in PASS_TAGS:
@@ -391,8 +433,11 @@ def main():
             continue
         ms = prof[tag]["mean_ms"]
         kname = prof[tag]["kernel"] or "?"
+        moved = moved_by_kernel.get(kname)
         passes[tag] = {"ms": round(ms, 4), "kernel": kname, "alg_GB": round(pb[tag] / 1e9, 4),
-                       "alg_GBps": round(pb[tag] / 1e6 / ms, 1), "frac": round(pb[tag] / 1e6 / ms / HBM_PEAK_GBS, 4)}
+                       "alg_GBps": round(pb[tag] / 1e6 / ms, 1), "frac": round(pb[tag] / 1e6 / ms / HBM_PEAK_GBS, 4),
+                       "moved_GB": round(moved / 1e9, 4) if moved else None,
+                       "moved_frac": round(moved / 1e6 / ms / HBM_PEAK_GBS, 4) if moved else None}
         fam = "k_spmm_*" if kname.startswith("k_spmm") else ("k_sddmm_*" if kname.startswith("k_sddmm") else kname)
         k = kern.setdefault(fam, {"ms": 0.0, "bytes": 0.0, "launches": 0, "names": set()})
         k["ms"] += ms; k["bytes"] += pb[tag]; k["launches"] += 1; k["names"].add(kname)
@@ -401,22 +446,7 @@ def main():
     dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else ("none", {"ms": 1.0, "bytes": 0.0, "launches": 1, "names": set()})
     dom_kernel = "/".join(sorted(dom["names"])) or dom_name
     achieved = dom["bytes"] / 1e6 / dom["ms"]          # GB/s = algorithmic bytes per launch / mean launch time
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    sha = kernels_sha()
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == "%s_h%d_d%d" % (name, h, d) and dom_kernel in tj.get("kernels", {}):
-                if tj.get("kernels_sha") == sha:
-                    traffic = tj["kernels"][dom_kernel]["hbm_bytes_per_launch"]
-                    traffic_src = ("NOT measured in this run: rocprofv3 --pmc passes of this command on the same kernel "
-                                   "sources (kernels_sha %s), profiles/pmc_traffic.json; %s" % (sha, tj.get("note", "")))
-                else:
-                    traffic_src = ("profiles/pmc_traffic.json was collected on other kernel sources (sha %s, now %s): "
-                                   "not quoted" % (tj.get("kernels_sha"), sha))
-        except (ValueError, KeyError):
-            pass
+    traffic, traffic_src = moved_by_kernel.get(dom_kernel), moved_note
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 # informative: against the 6.29 TB/s a device-wide copy reaches on this part
@@ -431,7 +461,9 @@ def main():
                          "frac_at_median_step": round(alg_step / 1e6 / statistics.median(step_ms) / HBM_PEAK_GBS, 4),
                          "kernel_ms_sum": round(sum(p["ms"] for p in passes.values()) +
                                                 sum(o["ms_per_step"] for o in other.values()), 3)},
-                "passes": passes, "other_launches": other}
+                "passes": passes, "passes_note": "frac = algorithmic bytes (API dtypes) / time / 8 TB/s; moved_GB / moved_frac = "
+                                                 "fabric-side bytes of the kernel family from the hardware counters: " + moved_note,
+                "other_launches": other}
     # tables far beyond the Infinity Cache with rows too short for column windows (products-shape): every
     # gathered edge is an HBM random-row read; what is physically reachable is that rate, not 8 TB/s of
     # algorithmic bytes -- a labelled secondary figure
@@ -465,6 +497,7 @@ def main():
             "ceiling_frac_of_hbm_roofline": round(alg_step / 1e6 / ceil_ms / HBM_PEAK_GBS, 4),
             "achieved_gather_GBps": round(gbytes / 1e6 / gms, 1) if gms > 0 else None,
             "frac_of_ceiling": round(ceil_ms / ms_per_step, 4)}
+        roofline["ceiling_frac"] = round(ceil_ms / ms_per_step, 4)   # = l2_gather_ceiling.ceiling_ms_per_step / ms_per_step
         roofline["gather_roofline"] = {
             "what": "secondary: the six gather passes' neighbour-row bytes over their measured time against the L2-resident "
                     "gather rate", "gather_bytes": int(gbytes), "peak_GBps": L2_GATHER_GBS,
@@ -493,6 +526,7 @@ def main():
            "graph": name, "nodes": n_rows, "edges": total_edges, "heads": h, "d": d,
            "chunk_size": args.chunk_size, "row_chunks": g.n_row_chunks, "col_chunks": g.n_col_chunks,
            "parallelism": ("single GPU" if not sharded else "node-range shards x%d, RCCL all-to-all halo" % n_parts)
+                          + (" [one-rank nccl process group, self-halo: the RCCL code path on one GPU]" if args.rccl_self else "")
                           + (" [TIMING-ONLY rehearsal of shard 0 of %d on one GPU, exchanges = local copies]" % args.emulate_world
                              if args.emulate_world > 1 and world == 1 else "")}
     if runner is not None:
@@ -507,6 +541,11 @@ def main():
             step()
         torch.cuda.synchronize()
         cfg["halo"]["exchange_ms"] = {k: round(1e3 * statistics.median(v), 3) for k, v in runner.timers.items()}
+        # --emulate-world: the "exchanges" are local copies of the right sizes on this GPU, NOT link times
+        cfg["halo"]["exchange_ms_is_local_copy"] = bool(runner.emulate)
+        if args.rccl_self:
+            cfg["halo"]["exchange_ms_note"] = ("one-rank RCCL process group: all_to_all_single from this GPU to itself (the real "
+                                               "collective code path, no xGMI link involved)")
         runner.timers = None
     metric = "edges/sec fwd+bwd (SDDMM+softmax+SpMM) on Reddit d=64; HBM GB/s vs roofline"
     if not (name == "reddit" and h == 1 and d == 64 and not sharded):
@@ -515,7 +554,7 @@ def main():
                   % (name, (" (one 1/%d node-range shard per GPU, BASELINE.json config %s)"
                             % (graphs.SHARDS_OF.get(name, n_parts), "4" if name == "papers100m" else "5" if name == "rmat25" else "-"))
                      if sharded else "-shape", h, d))
-    if world > 1:
+    if world > 1 or args.rccl_self:
         cfg["world_size"] = dist.get_world_size()
         cfg["backend"] = dist.get_backend()
     out = {
@@ -544,7 +583,7 @@ def main():
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.rccl_self:
         dist.destroy_process_group()
 
 

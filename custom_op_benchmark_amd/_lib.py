@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -51,6 +51,7 @@ _P = _vp
 _SIGNATURES = {
     "graphop_tune": [ctypes.c_char_p, ctypes.c_int],
     "graphop_tune_reset": [],
+    "graphop_check_device_errors": [],
     "graphop_tune_get": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "graphop_profile_enable": [ctypes.c_int],
     "graphop_profile_read": [ctypes.POINTER(ProfileRec), ctypes.c_int],
@@ -170,6 +171,15 @@ def check(rc):
     if rc != 0:
         msg = lib().graphop_last_error()
         raise RuntimeError("graphop: " + (msg.decode() if msg else "error %d" % rc))
+
+
+def check_errors(sync=True):
+    """Raise if a kernel of an earlier launch reported a failure through the device error word (a walk kernel whose
+    hand-over spin expired: include/graphop_hip.h, graphop_check_device_errors).  sync=True waits for the device
+    first, so every launch made so far is covered."""
+    if sync and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    check(lib().graphop_check_device_errors())
 
 
 def ptr(t):

@@ -33,7 +33,6 @@ SweepOpts attn_opts(int L, int NV, bool col, bool dry_run) {
   o.row_bytes = 2 * 16LL * L * NV;
   o.K = t.attn_k > 0 ? t.attn_k : (4 / NV > 0 ? 4 / NV : 1);
   o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
-  o.require_owner = 1;
   o.dry_run = dry_run ? 1 : 0;
   o.staged = attn_staged(L, NV) ? 1 : 0;
   o.stage_lds_per_group = (4 * L > 128 ? 4 * L : 128) * 2 * (int)sizeof(int);   // StageCfg<L, 1>::kLdsIntsPerGroup ints
@@ -56,9 +55,9 @@ int attn_fast_plan(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const
   int use_r = 0, use_c = 0;
   GO_DISPATCH_LNV((int)d, {
     SweepOpts o = attn_opts(L, NV, false, dry_run);
-    use_r = choose_sweep(plan_r, n_k, L, NV, st, &out->r, 0, true, &o);
+    use_r = choose_sweep(plan_r, n_k, L, NV, st, &out->r, true, &o);
     o = attn_opts(L, NV, true, dry_run);
-    if (use_r == 1) use_c = choose_sweep(plan_c, n_q, L, NV, st, &out->c, 0, true, &o);
+    if (use_r == 1) use_c = choose_sweep(plan_c, n_q, L, NV, st, &out->c, true, &o);
   });
   if (use_r < 0) return use_r;
   if (use_c < 0) return use_c;
@@ -92,8 +91,8 @@ bool attn_rows_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_q, i64 n_k, const 
       SweepLaunch sl;
       SweepOpts o;
       o.dry_run = 1;
-      o.bpc = sweep_bpc(NV, true, t.sweep_mode == 1);
-      windows = choose_sweep(plan_r, n_k, L, NV, st, &sl, 0, false, &o);
+      o.bpc = sweep_bpc(NV, true);
+      windows = choose_sweep(plan_r, n_k, L, NV, st, &sl, false, &o);
     });
     if (windows != 0) return false;
   }
@@ -197,7 +196,7 @@ int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool co
   GO_DISPATCH_LNV((int)d, {
     SweepLaunch sl;
     SweepOpts o = attn_opts(L, NV, col, true);
-    use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, true, &o);
+    use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, true, &o);
   });
   return use;
 }
@@ -248,6 +247,7 @@ int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indp
                               int64_t n_k, int64_t h, int64_t d, void* workspace,
                               int64_t workspace_bytes, const graphop_plan_t* plan, void* stream) {
   const char* fn = "attention_forward";
+  GO_TRY(check_async_error());
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
   GO_CHECK_ARG(n_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 && h >= 1 && d >= 0,
                "%s: negative size", fn);
@@ -286,6 +286,7 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
                                int64_t workspace_bytes, const graphop_plan_t* plan_r,
                                const graphop_plan_t* plan_c, void* stream) {
   const char* fn = "attention_backward";
+  GO_TRY(check_async_error());
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
   GO_CHECK_ARG(n_row_chunks >= 0 && n_col_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 &&
                h >= 1 && d >= 0, "%s: negative size", fn);

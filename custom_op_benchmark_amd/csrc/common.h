@@ -59,6 +59,11 @@ bool go_alloc_stream_ordered();   // true: a free needs no preceding stream sync
 // that names the remedy instead of letting the capture fail with an opaque HIP error.
 int check_not_capturing(hipStream_t st, const char* what);
 
+// Device-side failures (kernels_walk.h: walk_fail) are reported through one host-mapped word: kernels store a code,
+// the host looks at it at the start of every entry point and in graphop_check_device_errors (graphop_hip.hip).
+int* device_error_word(bool create);   // device-visible pointer (nullptr when there is none yet and !create)
+int check_async_error();               // GRAPHOP_OK, or GRAPHOP_ERR_HIP with the message set (the word is cleared)
+
 // ---- plan (host view) ---------------------------------------------------------------------------
 struct PlanStats {  // device-resident while the analysis kernels run, then copied back
   i64 unsorted;          // #positions with row[c] < row[c-1]
@@ -85,7 +90,6 @@ struct Sweep {
   int* vr_row = nullptr;  // [V] owning row id
   int* wp_lo = nullptr;   // [W*V] first slot of vrow v inside window w
   int* wp_hi = nullptr;   // [W*V] one past its last slot inside window w
-  int* sync = nullptr;    // [kSweepSyncInts] pacing counters (zeroed before every sweep launch)
   int* queues = nullptr;  // [kQueueRing][8 * 64] task-queue heads of the window-owner drivers
   unsigned queue_next = 0;  // next ring slot (taken under the plan's sweep mutex)
   // Window-major ("dealt") layouts of the window-owner tasks, one per lane-group geometry, built on
@@ -139,7 +143,6 @@ constexpr int kWalkK = 15;        // most rows per lane group: 15 x 256 B + a 1 
 constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)
-constexpr int kSweepSyncInts = 1 << 18;   // 64-int stride x (8 + 8 XCDs x up to 511 steps)
 // Every window-owner launch takes the next of kQueueRing sets of queue heads, so launches that
 // overlap on different streams never share one (a set is reused 64 launches later).
 constexpr int kQueueRing = 64;
@@ -162,9 +165,6 @@ struct graphop_plan {
   int32_t* eid32;          // [n_edges] (owned, optional; NULL when eid is the identity)
   int32_t* long_segs;      // [n_long] segments longer than kLongSegment slots (owned)
   int64_t n_long;
-  int32_t* inv32;          // [n_edges] slot holding edge id e (inverse of eid; lazily built, owned)
-  int inv_state;           // 0 = not tried, 1 = available, -1 = eid is not a permutation
-  float* scalar_scratch;   // [n_edges] per-call transposed edge scalars (lazily allocated, owned)
   int32_t* blk_seg;        // [n_dense_blocks + 1] first segment of every dense block (owned, optional)
   int32_t* seg_e0;         // [n_segments + 1] first slot of every segment (owned, with blk_seg)
   int32_t* seg_row;        // [n_segments] row id of every segment (owned, with blk_seg)
@@ -183,6 +183,27 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {   // two 32-bit DPP moves
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_t(float v) { return dpp_f32<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double dpp_t(double v) { return dpp_f64<CTRL>(v); }
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+  if constexpr (G >= 2) v += dpp_f64<0xB1>(v);
+  if constexpr (G >= 4) v += dpp_f64<0x4E>(v);
+  if constexpr (G >= 8) v += dpp_f64<0x141>(v);
+  if constexpr (G >= 16) v += dpp_f64<0x140>(v);
+  if constexpr (G >= 32) v += __shfl_xor(v, 16);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32);
+  return v;
 }
 
 // Sum over aligned groups of G lanes (G = 1..64, power of two); every lane gets the total.
@@ -251,35 +272,48 @@ template <int L, int U>
 __device__ __forceinline__ float group_bcast(float v) {
   return __builtin_bit_cast(float, group_bcast<L, U>(__builtin_bit_cast(int, v)));
 }
+template <int L, int U>
+__device__ __forceinline__ double group_bcast(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = group_bcast<L, U>((int)b), hi = group_bcast<L, U>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 
 // p[u] = this lane's partial of slot u's dot product.  Returns, in lane u of every group, the sum of
 // p[u] over the group's L lanes (other lanes: unspecified).  For a 16-lane group and 16 slots this is
 // a transpose-reduce: every step halves the number of live values (the lane keeps the slots whose
 // index bit matches its own lane bit and adds its partner's partials of those slots): 45 VALU
 // instructions instead of 16 x (4 DPP adds + a select) = 80.
-template <int L, int SB>
-__device__ __forceinline__ float group_dots_to_owner(float (&p)[SB], int l) {
-  if constexpr (L == 16 && SB == 16) {
-    float t8[8], t4[4], t2[2];
+template <int L, int SB, typename T>
+__device__ __forceinline__ T group_dots_to_owner(T (&p)[SB], int l) {
+  if constexpr ((L == 16 || L == 32) && SB == 16) {
+    // L == 32 (512-B rows): the two 16-lane halves of the group first exchange their partials (lane ^ 16), then each
+    // half runs the 16-lane tree: lanes u and u + 16 both end up with slot u's sum -- 16 cross-row exchanges + 45
+    // instructions instead of 16 x (4 DPP adds + a cross-row exchange + a select) = 96
+    if constexpr (L == 32) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) p[u] += __shfl_xor(p[u], 16);
+    }
+    T t8[8], t4[4], t2[2];
     const bool b3 = l & 8, b2 = l & 4, b1 = l & 2, b0 = l & 1;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float keep = b3 ? p[u + 8] : p[u], send = b3 ? p[u] : p[u + 8];
-      t8[u] = keep + dpp_f32<0x128>(send);      // row_ror:8 = lane ^ 8
+      const T keep = b3 ? p[u + 8] : p[u], send = b3 ? p[u] : p[u + 8];
+      t8[u] = keep + dpp_t<0x128>(send);        // row_ror:8 = lane ^ 8
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float keep = b2 ? t8[u + 4] : t8[u], send = b2 ? t8[u] : t8[u + 4];
-      t4[u] = keep + dpp_f32<0x141>(send);      // row_half_mirror: flips bits 0-2, keeps bit 3
+      const T keep = b2 ? t8[u + 4] : t8[u], send = b2 ? t8[u] : t8[u + 4];
+      t4[u] = keep + dpp_t<0x141>(send);        // row_half_mirror: flips bits 0-2, keeps bit 3
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const float keep = b1 ? t4[u + 2] : t4[u], send = b1 ? t4[u] : t4[u + 2];
-      t2[u] = keep + dpp_f32<0x4E>(send);       // quad_perm [2,3,0,1] = lane ^ 2
+      const T keep = b1 ? t4[u + 2] : t4[u], send = b1 ? t4[u] : t4[u + 2];
+      t2[u] = keep + dpp_t<0x4E>(send);         // quad_perm [2,3,0,1] = lane ^ 2
     }
-    const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
-    return keep + dpp_f32<0xB1>(send);          // quad_perm [1,0,3,2] = lane ^ 1
-  } else if constexpr (L == 16 && SB == 8) {   // lanes u and u + 8 both end up with slot u's sum
+    const T keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
+    return keep + dpp_t<0xB1>(send);            // quad_perm [1,0,3,2] = lane ^ 1
+  } else if constexpr (L == 16 && SB == 8 && sizeof(T) == 4) {   // lanes u and u + 8 both end up with slot u's sum
     // Same summation tree as the 16-slot form (pairs {l, l^8} first, then ^7, ^2, ^1), so a dot
     // product recomputed by an 8-slot strip is BITWISE the value a 16-slot strip stored: the fused
     // attention backward re-derives exp(s - m) from the forward's row maxima.
@@ -300,10 +334,10 @@ __device__ __forceinline__ float group_dots_to_owner(float (&p)[SB], int l) {
     const float keep = b0 ? t2[1] : t2[0], send = b0 ? t2[0] : t2[1];
     return keep + dpp_f32<0xB1>(send);
   } else {
-    float res = 0.f;
+    T res = 0;
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-      const float s = group_sum<L>(p[u]);
+      const T s = group_sum<L>(p[u]);
       if (l == u) res = s;
     }
     return res;

@@ -124,7 +124,6 @@ int* plan_take_queue(graphop_plan*, const Sweep*);
 int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
-int plan_get_inverse(graphop_plan*, hipStream_t);
 int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**);
 int plan_build_seg_eptr(graphop_plan*, hipStream_t);
 int* plan_take_walk_sync(graphop_plan*, const Walk*);
@@ -157,6 +156,40 @@ hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- device-side error word ----------------------------------------------------------------------------
+static int* g_err_host = nullptr;   // hipHostMalloc'ed (mapped, coherent): written by kernels, read here
+static int* g_err_dev = nullptr;
+static std::mutex g_err_mu;
+int* device_error_word(bool create) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  if (!g_err_host && create) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+      memset(h, 0, 64);
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) { g_err_host = (int*)h; g_err_dev = (int*)d; }
+      else (void)hipHostFree(h);
+    }
+    (void)hipGetLastError();
+  }
+  return g_err_dev;
+}
+int check_async_error() {
+  int code = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    if (!g_err_host) return GRAPHOP_OK;
+    code = __atomic_exchange_n(g_err_host, 0, __ATOMIC_ACQ_REL);
+  }
+  if (code == 0) return GRAPHOP_OK;
+  const char* what = code == kWalkErrQuad ? "a (step, quad) unit waited for its quad's previous step"
+                   : code == kWalkErrRing ? "a worker wave waited for a ring chunk of its feeder wave"
+                   : code == kWalkErrFeeder ? "a feeder wave waited for ring space" : "unknown code";
+  set_error("a walk kernel (k_spmm_walk_f32) of an earlier launch aborted: %s until its spin bound expired (device "
+            "error code %d); the outputs of that launch are invalid", what, code);
+  return GRAPHOP_ERR_HIP;
+}
+
 namespace {
 
 // Chunks per lane group of the chunk drivers: the tuned value amortises row switches on big graphs,
@@ -184,12 +217,17 @@ inline bool fast_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_src_rows) {
   return true;
 }
 
-// Decide whether the window-sweep driver applies and fetch / build its structure.
-// Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
+// fp64 on the plan-driven kernels (kernels_walk.h / kernels_strip.h are written against 16-byte row pieces): one head,
+// rows of 256 B, 512 B or 1 KB -- the lane-group shapes of fp32 d = 64 / 128 / 256
+inline bool fast64_ok(int dtype, i64 h, i64 d, i64 n_edges, i64 n_src_rows) {
+  if (tuning().force_generic || dtype != GRAPHOP_F64 || h != 1) return false;
+  if (d != 32 && d != 64 && d != 128) return false;
+  return n_edges < 0x7fffffffLL && n_src_rows < 0x7fffffffLL;
+}
 }  // namespace
 
 int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
-                 SweepLaunch* out, int force_windows, bool accumulating, const SweepOpts* opts) {
+                 SweepLaunch* out, bool accumulating, const SweepOpts* opts) {
   const Tuning& t = tuning();
   if (!t.sweep || !plan) return 0;
   const graphop_plan_info_t& pi = plan->info;
@@ -198,8 +236,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
   const i64 row_bytes = (opts && opts->row_bytes > 0) ? opts->row_bytes : 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
-  if (!force_windows && table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
-  if (opts && opts->require_owner && (t.sweep_mode != 1 || force_windows)) return 0;
+  if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
   // Two tiers.  L2-sized windows (<= 4 MB) while a (row, window) granule still holds a few slots;
   // otherwise, for tables that do not fit the 256 MiB Infinity Cache next to the streams, 32 MB
   // windows that stay Infinity-Cache resident (HBM-rate random row gathers become Infinity-Cache-
@@ -211,21 +248,20 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   // A window-owner SpMM over identity-eid slots flushes one partial row per (vrow, window): it is
   // faster with windows of twice the L2 size (half as many flushes, misses served by the Infinity
   // Cache) and vrows twice as long -- measured on Reddit-shape: 2.25 ms at W=8 vs 2.46 at W=16.
-  int coarse = (accumulating && t.sweep_mode == 1 && !force_windows && pi.eid_identity &&
-                t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
+  int coarse = (accumulating && pi.eid_identity && t.spmm_window_scale > 1) ? t.spmm_window_scale : 1;
   // the fused kernels state their window size directly (their packed rows are twice as wide)
   const i64 win_kb = (opts && opts->window_scale > 0) ? (i64)t.window_kb * opts->window_scale : (i64)t.window_kb;
   if (opts && opts->window_scale > 0) coarse = 1;
-  i64 W = force_windows ? force_windows : pow2ceil(ceil_div(table_bytes, win_kb * 1024));
-  if (!force_windows && t.sweep_w > 0) W = t.sweep_w;   // experiments: window count given directly
-  if (!force_windows && !windows_ok(W)) {
+  i64 W = pow2ceil(ceil_div(table_bytes, win_kb * 1024));
+  if (t.sweep_w > 0) W = t.sweep_w;   // experiments / tests: window count given directly
+  if (!windows_ok(W)) {
     coarse = 1;   // Infinity-Cache tier: windows are sized for that cache, not for the flush count
     W = table_bytes > (128LL << 20) ? pow2ceil(ceil_div(table_bytes, (i64)t.mall_window_kb * 1024)) : 0;
     if (!windows_ok(W)) return 0;
-  } else if (!force_windows && t.sweep_w <= 0 && coarse > 1) {
+  } else if (t.sweep_w <= 0 && coarse > 1) {
     const i64 Wc = pow2ceil(ceil_div(table_bytes, (i64)t.window_kb * 1024 * coarse));
     if (Wc >= 2) W = Wc; else coarse = 1;
-  } else if (!force_windows && t.sweep_w <= 0 && !accumulating && !(opts && opts->window_scale > 0) && row_bytes >= 1024) {
+  } else if (t.sweep_w <= 0 && !accumulating && !(opts && opts->window_scale > 0) && row_bytes >= 1024) {
     // 1-KB rows: 4 MB windows leave a (row, window) granule with half a batch of slots and one A-row fetch per
     // 8 gathered rows; windows of twice the L2 size measure 7 % faster (Reddit-shape d = 256: 8.08 -> 7.49 ms)
     while (W > 2 && mean_row < 12 * W) W >>= 1;
@@ -237,7 +273,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   // passes that gather their per-slot scalars through eid (the column-major ones) run with half
   // the vrows per lane group: the columns in flight on an XCD then span half as many ids, and more
   // of the scalar lines they share are still in L2 (Reddit-shape: 3.27 -> 3.06 ms per pass)
-  if (t.sweep_k <= 0 && !(opts && opts->K > 0) && !pi.eid_identity && t.sweep_mode == 1 && !force_windows && K > 1) K /= 2;
+  if (t.sweep_k <= 0 && !(opts && opts->K > 0) && !pi.eid_identity && K > 1) K /= 2;
   if (K > L) K = L;
   const int gpb = kFastBlock / L;
   const int bpc_req = (opts && opts->bpc > 0) ? (opts->bpc < t.sweep_bpc || opts->window_scale > 0 ? opts->bpc : t.sweep_bpc)
@@ -257,79 +293,42 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   const int rc = plan_get_sweep(const_cast<graphop_plan*>(plan), (int)W, win_cols, T, st, &sw);
   if (rc != GRAPHOP_OK) return -rc;
   if (!sw) return 0;   // the plan already holds its share of window geometries: chunk drivers for this one
-  out->window_owner = t.sweep_mode == 1 && !force_windows;
-  if (out->window_owner) {
-    // window-owner drivers: a resident grid of waves pulling (window, vrow tile) tasks from the
-    // eight per-XCD queue heads (sync[y * 64], zeroed here)
-    const int tile = (kWave / L) * K;
-    const i64 tiles = ceil_div(sw->V, tile);
-    if (tiles * ceil_div((i64)sw->W, 8) >= 0x7fffffffLL) return 0;
-    out->view = SweepView{};
-    out->view.wp_lo = sw->wp_lo;
-    out->view.wp_hi = sw->wp_hi;
-    out->view.vr_row = sw->vr_row;
-    out->view.idx32 = plan->idx32;
-    out->view.eid32 = plan->eid32;
-    const bool dry = opts && opts->dry_run;
-    out->view.sync = dry ? nullptr : plan_take_queue(const_cast<graphop_plan*>(plan), sw);
-    out->view.V = sw->V;
-    out->view.W = sw->W;
-    out->view.K = K;
-    out->view.win_bytes = win_cols * row_bytes;
-    out->view.table_bytes = table_bytes;
-    out->view.touch = opts ? opts->touch : 0;
-    if (!dry && zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
-    i64 nb = (i64)t.n_cu * bpc;
-    const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
-    if (nb > need) nb = need;
-    out->blocks = (unsigned)(nb < 1 ? 1 : nb);
-    out->lds_bytes = (size_t)gpb * K * row_bytes;
-    if (opts && opts->staged) {
-      const Sweep::Dealt* dl = nullptr;
-      const int rcd = plan_get_dealt(const_cast<graphop_plan*>(plan), sw, L, K, st, &dl);
-      if (rcd != GRAPHOP_OK) return -rcd;
-      if (dl) {
-        out->view.rec = (const int4*)dl->rec;
-        out->view.ids_w = dl->ids;
-        out->view.eids_w = dl->eids;
-        out->lds_bytes += (size_t)gpb * opts->stage_lds_per_group;
-      }
-    }
-    return 1;
-  }
-  // grid: a multiple of 8 workgroups; XCD slot x (= blockIdx % 8) owns vrows [x*vx, (x+1)*vx)
-  i64 blocks = (i64)t.n_cu * bpc;
-  blocks -= blocks % 8;
-  int slots = 8;
-  i64 vx = ceil_div(ceil_div(sw->V, slots), K) * K;
-  i64 rounds = ceil_div(vx, (blocks / slots) * gpb * K);
-  if (rounds <= 1) {
-    rounds = 1;
-    blocks = ceil_div(ceil_div(vx, K), gpb) * slots;
-  }
-  out->view.win_bytes = win_cols * row_bytes;
-  out->view.table_bytes = table_bytes;
-  // one 128-B line per thread of an XCD slot's workgroups must cover a window
-  out->view.prefetch = (t.sweep_prefetch && (blocks / slots) * kFastBlock * 128 >= win_cols * row_bytes) ? 1 : 0;
-  out->view.xcd_slots = slots;
-  out->view.vx = (int)vx;
+  // a resident grid of waves pulling (window, vrow tile) tasks from the eight per-XCD queue heads
+  // (sync[y * 64], zeroed here)
+  const int tile = (kWave / L) * K;
+  const i64 tiles = ceil_div(sw->V, tile);
+  if (tiles * ceil_div((i64)sw->W, 8) >= 0x7fffffffLL) return 0;
+  out->view = SweepView{};
   out->view.wp_lo = sw->wp_lo;
   out->view.wp_hi = sw->wp_hi;
   out->view.vr_row = sw->vr_row;
   out->view.idx32 = plan->idx32;
   out->view.eid32 = plan->eid32;
-  const i64 sync_ints = 64LL * (8 + 16 * rounds * sw->W);  // kSyncStride * (kSyncXcds + 2 * xcds * steps)
-  const bool paced = t.sweep_drift > 0 && sync_ints <= kSweepSyncInts;
-  out->view.sync = paced ? sw->sync : nullptr;
-  out->view.drift = paced ? (t.sweep_drift > 3 ? 3 : t.sweep_drift) : 0;   // pacer's LDS ring holds 4 steps
-  if (paced && zero_async(sw->sync, sizeof(int) * (size_t)sync_ints, st) != hipSuccess)
-    return -GRAPHOP_ERR_HIP;
+  const bool dry = opts && opts->dry_run;
+  out->view.sync = dry ? nullptr : plan_take_queue(const_cast<graphop_plan*>(plan), sw);
   out->view.V = sw->V;
   out->view.W = sw->W;
   out->view.K = K;
-  out->view.rounds = (int)rounds;
-  out->blocks = (unsigned)blocks;
+  out->view.win_bytes = win_cols * row_bytes;
+  out->view.table_bytes = table_bytes;
+  out->view.touch = opts ? opts->touch : 0;
+  if (!dry && zero_async(out->view.sync, sizeof(int) * kQueueInts, st) != hipSuccess) return -GRAPHOP_ERR_HIP;
+  i64 nb = (i64)t.n_cu * bpc;
+  const i64 need = ceil_div(tiles * sw->W, (i64)(kFastBlock / kWave));
+  if (nb > need) nb = need;
+  out->blocks = (unsigned)(nb < 1 ? 1 : nb);
   out->lds_bytes = (size_t)gpb * K * row_bytes;
+  if (opts && opts->staged) {
+    const Sweep::Dealt* dl = nullptr;
+    const int rcd = plan_get_dealt(const_cast<graphop_plan*>(plan), sw, L, K, st, &dl);
+    if (rcd != GRAPHOP_OK) return -rcd;
+    if (dl) {
+      out->view.rec = (const int4*)dl->rec;
+      out->view.ids_w = dl->ids;
+      out->view.eids_w = dl->eids;
+      out->lds_bytes += (size_t)gpb * opts->stage_lds_per_group;
+    }
+  }
   return 1;
 }
 
@@ -344,8 +343,9 @@ inline bool sddmm_staged_heads(int L, int NV, i64 h, i64 n_edges) {
   return d4 == 4 || d4 == 8 || d4 == 16 || d4 == 32;
 }
 inline bool sddmm_staged(const graphop_plan* plan, int L, int NV, i64 h, i64 n_table_rows) {
-  return (tuning().staged_ids & 1) && (h == 1 || sddmm_staged_heads(L, NV, h, plan->info.n_edges)) &&
-         plan->info.eid_identity && table_off32(n_table_rows, L, NV);
+  // one head: tables of 4 GiB and more too (64-bit row offsets, kernels_strip.h); several heads: 32-bit offsets only
+  return (tuning().staged_ids & 1) && plan->info.eid_identity &&
+         (h == 1 || (sddmm_staged_heads(L, NV, h, plan->info.n_edges) && table_off32(n_table_rows, L, NV)));
 }
 inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
   return (tuning().staged_ids & 2) && h == 1 && table_off32(n_table_rows, L, NV);
@@ -404,12 +404,9 @@ struct WalkDebug {
 
 // Decide whether the walk drivers apply to a pass over `plan` that gathers rows of 16*L*NV bytes from a
 // table of n_table_rows rows, and fetch / build the layout.  1 = use it, 0 = no, < 0 = error (negated).
-// `SH` = lane groups per bin of the layout (kernels_walk.h): 1 for the SpMM-type kernel, the lane groups of a
-// wave for the SDDMM-type kernel.
 // `K` = rows per lane group the kernel's LDS holds.
 template <int L, int NV>
-int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int worker_threads, int wgs_per_cu, hipStream_t st,
-                WalkLaunch* out, bool dry_run = false) {
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
   if constexpr (NV != 1 || L < 16) {
     return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
   } else {
@@ -418,8 +415,8 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int w
     const graphop_plan_info_t& pi = plan->info;
     if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
     if (!pi.eid_identity && !plan->eid32) return 0;
-    if (pi.n_segments == 0 || pi.n_edges == 0 || !table_off32(n_table_rows, L, NV)) return 0;
-    if (pi.max_index >= (1LL << kWalkKShift)) return 0;
+    if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
+    if (pi.max_index >= (1LL << kWalkKShift) || n_table_rows > (1LL << kWalkKShift)) return 0;   // ids share a word with the row-in-bin
     const i64 table_bytes = n_table_rows * 16LL * L * NV;
     if (table_bytes < (i64)t.sweep_min_kb * 1024) return 0;
     // column-major passes: 2 MB windows at 256-B rows (the scalar lines share the L2), 4 MB from 1-KB rows on
@@ -430,16 +427,15 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int w
     if (W > t.max_windows || W > 512) return 0;
     const i64 mean_row = pi.n_edges / pi.n_segments;
     if (mean_row < (i64)t.sweep_min_granule * W / 2) return 0;
-    const int GPB = worker_threads / L;
-    i64 blocks = t.walk_blocks > 0 ? ceil_div((i64)t.walk_blocks * kFastBlock, worker_threads) : (i64)t.n_cu * wgs_per_cu;
+    const int GPB = kWalkWorkers / L;
+    i64 blocks = t.walk_blocks > 0 ? ceil_div((i64)t.walk_blocks * kFastBlock, kWalkWorkers) : (i64)t.n_cu;   // one workgroup per CU
     int slots = 8;
     if (blocks >= 8) blocks -= blocks % 8; else slots = 1;
     const i64 groups = blocks * GPB;
     if (pi.n_edges < groups * (i64)t.walk_min_bin) return 0;
-    static_assert(walk_lds_bytes<L, NV>() <= 160 * 1024 / kWalkBpc, "LDS per CU");
     if (K < 1 || K > kWalkK) return 0;
     const Walk* wk = nullptr;
-    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, SH, K,
+    const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, /*lane groups per bin=*/1, K,
                                  slots, st, &wk);
     if (rc != GRAPHOP_OK) return -rc;
     if (!wk) return 0;
@@ -457,9 +453,11 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int w
     out->view.drift = t.walk_drift;
     out->view.sync = (t.walk_drift > 0 && !dry_run) ? plan_take_walk_sync(const_cast<graphop_plan*>(plan), wk) : nullptr;
     out->view.dbg = nullptr;
+    out->view.err = device_error_word(false);   // (created with the plan's first walk layout, never during a capture)
+    out->view.fault = t.walk_fault;
     out->view.stream_weights = pi.eid_identity ? 1 : 0;
     out->blocks = (unsigned)blocks;
-    out->lds_bytes = walk_lds_bytes<L, NV>();
+    out->lds_bytes = 0;   // (set by the launcher: depends on the heads)
     if (!dry_run && out->view.sync &&
         zero_async(out->view.sync, sizeof(int) * 64 * (size_t)(8 + 16 * (i64)wk->rounds * out->view.steps), st) != hipSuccess)
       return -GRAPHOP_ERR_HIP;
@@ -467,72 +465,65 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int SH, int K, int w
   }
 }
 
-template <int L, int NV>
-int try_sddmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A, const void* B,
-                   void* y, i64 h, hipStream_t st) {
-  if constexpr (NV != 1 || L < 16) {
-    return 0;
-  } else {
-    if (!(tuning().walk & 1) || h != 1 || !plan) return 0;
-    WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kWalkK, kFastBlock, kWalkBpc, st, &wl);
-    if (use != 1) return use;
-    static const bool attr = hipFuncSetAttribute((const void*)k_sddmm_walk_f32<L, NV>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / kWalkBpc) == hipSuccess;
-    (void)attr;
-    WalkDebug dbg;
-    dbg.arm(&wl, tag, st);
-    ProfScope prof(tag, st, "k_sddmm_walk_f32");
-    hipLaunchKernelGGL((k_sddmm_walk_f32<L, NV>), dim3(wl.blocks), dim3(kFastBlock), wl.lds_bytes, st, wl.view,
-                       (const float*)A, (const float*)B, (float*)y);
-    return 1;
-  }
-}
-
 // Rows per lane group of the SpMM-type walk kernel for `h` heads (0 = the pass does not take the walk): what the
 // LDS holds next to the per-head weight rings, at least 8 (fewer rows = more rounds = more table streams).
 template <int L, int NV>
-inline int spmm_walk_k(i64 h) {
+inline int spmm_walk_k(i64 h, int dtype = GRAPHOP_F32) {
   if (h != 1 && h != 2 && h != 4 && h != 8) return 0;
+  if (dtype == GRAPHOP_F64 && h != 1) return 0;                                    // fp64: one head
   if (h > 1 && (NV != 1 || (4 * L) % h != 0 || (4 * L / h) % 4 != 0)) return 0;   // a lane's float4 lies inside one head
-  const int k = spmm_walk_rows<L, NV>((int)h);
+  const int k = spmm_walk_rows<L, NV>((int)h, dtype == GRAPHOP_F64 ? 2 : 1);
   return k >= 8 ? k : 0;
 }
 
 template <int L, int NV>
-int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w, const void* X,
+int try_spmm_walk(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows, const void* w, const void* X,
                   void* out, i64 h, int d4, hipStream_t st) {
   if constexpr (NV != 1 || L < 16) {
     return 0;
   } else {
     if (!plan) return 0;
     if (!(tuning().walk & (plan->info.eid_identity ? 2 : 4))) return 0;
-    const int K = spmm_walk_k<L, NV>(h);
+    const int K = spmm_walk_k<L, NV>(h, dtype);
     if (K == 0 || (h > 1 && !aligned16(w))) return 0;
+    const bool off32 = table_off32(n_table_rows, L, NV);
+    if (h > 1 && !off32) return 0;   // several heads: 32-bit row offsets only
     WalkLaunch wl;
-    const int use = choose_walk<L, NV>(plan, n_table_rows, 1, K, kWalkWorkers, 1, st, &wl);
+    const int use = choose_walk<L, NV>(plan, n_table_rows, K, st, &wl);
     if (use != 1) return use;
     WalkDebug dbg;
     dbg.arm(&wl, tag, st, kWalkWorkers / kWave);
-    ProfScope prof(tag, st, "k_spmm_walk_f32");
+    ProfScope prof(tag, st, dtype == GRAPHOP_F64 ? "k_spmm_walk_f64" : "k_spmm_walk_f32");
+    auto launch = [&](auto kfn, size_t lds_bytes, auto... args) {
+      // (the attribute is per kernel function: set it on every launch path once)
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      if (tuning().walk_debug) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kfn, kWalkThreads, lds_bytes);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, (const void*)kfn);
+        fprintf(stderr, "[walk] occupancy API: %d workgroups of %d threads per CU (dynamic LDS %zu, static %zu, regs %d, K %d)\n", nb,
+                kWalkThreads, lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs, K);
+      }
+      hipLaunchKernelGGL(kfn, dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view, args...);
+    };
+    if (dtype == GRAPHOP_F64) {
+      if constexpr (spmm_walk_rows<L, NV>(1, 2) >= 8) {
+        const size_t lds_bytes = spmm_walk_lds_bytes<L, NV>(K, 1, 2);
+        if (off32) launch(k_spmm_walk_f64<L, NV, true>, lds_bytes, (const double*)w, (const double*)X, (double*)out);
+        else launch(k_spmm_walk_f64<L, NV, false>, lds_bytes, (const double*)w, (const double*)X, (double*)out);
+      }
+      return 1;
+    }
     auto go = [&](auto hc) {
       constexpr int HV = decltype(hc)::value;
       if constexpr (spmm_walk_rows<L, NV>(HV) < 8) return;    // (spmm_walk_k said no: never instantiated)
       else {
-      static const bool attr = hipFuncSetAttribute((const void*)k_spmm_walk_f32<L, NV, HV>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
-      (void)attr;
-      const size_t lds_bytes = spmm_walk_lds_bytes<L, NV>(K, HV);
-      if (tuning().walk_debug) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_spmm_walk_f32<L, NV, HV>, kWalkThreads, lds_bytes);
-        hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, (const void*)k_spmm_walk_f32<L, NV, HV>);
-        fprintf(stderr, "[walk] occupancy API: %d workgroups of %d threads per CU (dynamic LDS %zu, static %zu, regs %d, K %d)\n", nb,
-                kWalkThreads, lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs, K);
-      }
-      hipLaunchKernelGGL((k_spmm_walk_f32<L, NV, HV>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view,
-                         (const float*)w, (const float*)X, (float*)out, d4);
+        const size_t lds_bytes = spmm_walk_lds_bytes<L, NV>(K, HV);
+        if constexpr (HV == 1) {
+          if (!off32) { launch(k_spmm_walk_f32<L, NV, 1, false>, lds_bytes, (const float*)w, (const float*)X, (float*)out, d4); return; }
+        }
+        launch(k_spmm_walk_f32<L, NV, HV, true>, lds_bytes, (const float*)w, (const float*)X, (float*)out, d4);
       }
     };
     switch ((int)h) {
@@ -546,28 +537,41 @@ int try_spmm_walk(const char* tag, const graphop_plan* plan, i64 n_table_rows, c
 }
 
 template <int L, int NV>
-int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* A,
+int try_sddmm_sweep(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows, const void* A,
                     const void* B, void* y, i64 h, int d4, hipStream_t st) {
   SweepLaunch sl;
   SweepOpts so;
-  so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  const bool f64 = dtype == GRAPHOP_F64;
+  if (f64 && (h != 1 || NV != 1 || L < 16 || !sddmm_staged(plan, L, NV, h, n_table_rows))) return 0;   // fp64: the staged strip only
+  const bool off32 = table_off32(n_table_rows, L, NV);   // table < 4 GiB: 32-bit byte offsets
+  so.bpc = (f64 || !off32) ? 3 : sweep_bpc(NV, h == 1);
   so.touch = tuning().touch_sddmm;
   const bool id = plan->info.eid_identity != 0;
-  const bool off32 = table_off32(n_table_rows, L, NV);   // table < 4 GiB: 32-bit byte offsets
   so.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
   so.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int) + (h > 1 ? 64 * (int)h : 0);   // + [16 slots][h] results
   if (h > 1 && !aligned16(y)) so.staged = false;
-  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, false, &so);
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, false, &so);
   if (use != 1) return use;
-  const bool staged = sl.window_owner && sl.view.rec != nullptr;
-  ProfScope prof(tag, st, staged ? "k_sddmm_wown_staged_f32" : sl.window_owner ? "k_sddmm_wown_f32" : "k_sddmm_sweep_f32");
+  const bool staged = sl.view.rec != nullptr;
+  if (f64 && !staged) return 0;     // (no dealt layout: the caller falls back to the generic kernels; nothing launched yet)
+  ProfScope prof(tag, st, f64 ? "k_sddmm_wown_staged_f64" : staged ? "k_sddmm_wown_staged_f32" : "k_sddmm_wown_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
+  if (f64) {
+    if constexpr (NV == 1 && L >= 16) {
+      if (off32) hipLaunchKernelGGL((k_sddmm_wown_staged_f64<L, NV, true>), grid, block, sl.lds_bytes, st, sl.view,
+                                    (const double*)A, (const double*)B, (double*)y);
+      else hipLaunchKernelGGL((k_sddmm_wown_staged_f64<L, NV, false>), grid, block, sl.lds_bytes, st, sl.view,
+                              (const double*)A, (const double*)B, (double*)y);
+    }
+    return 1;
+  }
   const float* a = (const float*)A;
   const float* b = (const float*)B;
   float* yy = (float*)y;
   if (staged) {
     if (h == 1) {
-      hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+      if (off32) hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV, 0, true>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
+      else hipLaunchKernelGGL((k_sddmm_wown_staged_f32<L, NV, 0, false>), grid, block, sl.lds_bytes, st, sl.view, a, b, yy);
     } else if constexpr (NV == 1 && L >= 16) {
       auto go = [&](auto dc) {
         constexpr int D4 = decltype(dc)::value;
@@ -583,15 +587,9 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
     }
     return 1;
   }
-#define GO_K(H1, ID, O32)                                                                          \
-  do {                                                                                             \
-    if (sl.window_owner)                                                                           \
-      hipLaunchKernelGGL((k_sddmm_wown_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,    \
-                         sl.view, a, b, yy, (int)h, d4);                                           \
-    else                                                                                           \
-      hipLaunchKernelGGL((k_sddmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,   \
-                         sl.view, a, b, yy, (int)h, d4);                                           \
-  } while (0)
+#define GO_K(H1, ID, O32)                                                                      \
+  hipLaunchKernelGGL((k_sddmm_wown_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,    \
+                     sl.view, a, b, yy, (int)h, d4)
   if (h == 1) {
     if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
     else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
@@ -602,76 +600,32 @@ int try_sddmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows,
   return 1;
 }
 
-// Column-major pass helper: transpose the per-slot scalars w (indexed by edge id) into slot order
-// of `plan` with a paced scatter over the OTHER (row-major, identity-eid) orientation's sweep.
-// Returns 1 and sets *w_slot when done, 0 when not applicable, <0 on error.
-inline int transpose_scalars(const graphop_plan* plan, const graphop_plan* other, i64 n_other_cols,
-                             const float* w, hipStream_t st, const float** w_slot) {
-  const Tuning& t = tuning();
-  if (!t.transpose_scalars || !plan || !other || plan->info.eid_identity || !plan->eid32) return 0;
-  if (!other->info.eid_identity || other->info.n_edges != plan->info.n_edges || n_other_cols <= 0) return 0;
-  graphop_plan* p = const_cast<graphop_plan*>(plan);
-  const int rc = plan_get_inverse(p, st);
-  if (rc != GRAPHOP_OK) return -rc;
-  if (p->inv_state != 1) return 0;
-  // windows sized so that one (XCD vrow range, window) step writes ~2 MB of the slot-order array
-  i64 Ws = pow2ceil(ceil_div(plan->info.n_edges * 4, 8LL * (2 << 20)));
-  if (Ws < 2) Ws = 2;
-  if (Ws > t.max_windows) Ws = t.max_windows;
-  SweepLaunch sl;
-  SweepOpts so;
-  so.bpc = sweep_bpc(1, true, false);
-  const int use = choose_sweep(other, n_other_cols, 16, 1, st, &sl, (int)Ws, false, &so);
-  if (use != 1) return use;
-  ProfScope prof("transpose_scalars", st);
-  hipLaunchKernelGGL((k_scatter_scalars_sweep<16>), dim3(sl.blocks), dim3(kFastBlock), 0, st, sl.view,
-                     (const int*)p->inv32, w, p->scalar_scratch);
-  *w_slot = p->scalar_scratch;
-  return 1;
-}
-
 template <int L, int NV>
 int try_spmm_sweep(const char* tag, const graphop_plan* plan, i64 n_table_rows, const void* w,
-                   const void* X, void* out, i64 h, int d4, const graphop_plan* other,
-                   i64 n_other_cols, hipStream_t st) {
+                   const void* X, void* out, i64 h, int d4, hipStream_t st) {
   SweepLaunch sl;
   SweepOpts so;
-  so.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+  so.bpc = sweep_bpc(NV, h == 1);
   const bool off32 = table_off32(n_table_rows, L, NV);
-  constexpr bool kStagedOk = true;
   so.staged = spmm_staged(L, NV, h, n_table_rows);
-  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &so);
+  const int use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, /*accumulating=*/true, &so);
   if (use != 1) return use;
-  bool id = plan->info.eid_identity != 0;
+  const bool id = plan->info.eid_identity != 0;
   const float* ww = (const float*)w;
-  if (!id && h == 1) {   // column-major pass: read the weights in slot order after a blocked transpose
-    const float* w_slot = nullptr;
-    const int tr = transpose_scalars(plan, other, n_other_cols, ww, st, &w_slot);
-    if (tr < 0) return tr;
-    if (tr == 1) { ww = w_slot; id = true; }
-  }
-  const bool staged = sl.window_owner && sl.view.rec != nullptr && (id || sl.view.eids_w != nullptr);
-  ProfScope prof(tag, st, staged ? "k_spmm_wown_staged_f32" : sl.window_owner ? "k_spmm_wown_f32" : "k_spmm_sweep_f32");
+  const bool staged = sl.view.rec != nullptr && (id || sl.view.eids_w != nullptr);
+  ProfScope prof(tag, st, staged ? "k_spmm_wown_staged_f32" : "k_spmm_wown_f32");
   const dim3 grid(sl.blocks), block(kFastBlock);
   const float* x = (const float*)X;
   float* o = (float*)out;
-  if constexpr (kStagedOk) {
-    if (staged) {
-      const size_t lds = (size_t)(kFastBlock / L) * (id ? StageCfg<L, 1>::kLdsIntsPerGroup : StageCfg<L, 2>::kLdsIntsPerGroup) * sizeof(int);
-      if (id) hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, true>), grid, block, lds, st, sl.view, ww, x, o);
-      else hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, false>), grid, block, lds, st, sl.view, ww, x, o);
-      return 1;
-    }
+  if (staged) {
+    const size_t lds = (size_t)(kFastBlock / L) * (id ? StageCfg<L, 1>::kLdsIntsPerGroup : StageCfg<L, 2>::kLdsIntsPerGroup) * sizeof(int);
+    if (id) hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, true>), grid, block, lds, st, sl.view, ww, x, o);
+    else hipLaunchKernelGGL((k_spmm_wown_staged_f32<L, NV, false>), grid, block, lds, st, sl.view, ww, x, o);
+    return 1;
   }
-#define GO_K(H1, ID, O32)                                                                          \
-  do {                                                                                             \
-    if (sl.window_owner)                                                                           \
-      hipLaunchKernelGGL((k_spmm_wown_f32<L, NV, H1, ID, O32>), grid, block, 0, st, sl.view, ww,   \
-                         x, o, (int)h, d4);                                                        \
-    else                                                                                           \
-      hipLaunchKernelGGL((k_spmm_sweep_f32<L, NV, H1, ID, O32>), grid, block, sl.lds_bytes, st,    \
-                         sl.view, ww, x, o, (int)h, d4);                                           \
-  } while (0)
+#define GO_K(H1, ID, O32)                                                                      \
+  hipLaunchKernelGGL((k_spmm_wown_f32<L, NV, H1, ID, O32>), grid, block, 0, st, sl.view, ww,   \
+                     x, o, (int)h, d4)
   if (h == 1) {
     if (id) { if (off32) GO_K(true, true, true); else GO_K(true, true, false); }
     else { if (off32) GO_K(true, false, true); else GO_K(true, false, false); }
@@ -758,16 +712,22 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
   if constexpr (!EDGE_B) {
     if (try_sddmm_block(tag, dtype, plan, n_src_rows, A, B, y, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
   }
+  // fp64 with a plan: the staged window-owner strip at rows of 256 B - 1 KB (d = 32 / 64 / 128), else the generic kernels
+  if constexpr (!EDGE_B) {
+    if (plan && fast64_ok(dtype, h, d, E, n_src_rows)) {
+      int use = 0;
+      GO_DISPATCH_LNV((int)(2 * d), { use = try_sddmm_sweep<L, NV>(tag, dtype, plan, n_src_rows, A, B, y, h, 0, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+    }
+  }
   // EDGE_B (node_mul_edge): B rows are d wide, A rows h*d wide -> fast path only for h == 1
   if (fast_ok(dtype, h, d, E, n_src_rows) && (!EDGE_B || h == 1)) {
     const int cpg = cpg_for(C, tuning().sddmm_cpg, (int)(h * d));
     const int F = (int)(h * d), d4 = (int)(d / 4);
     if constexpr (!EDGE_B) {
       int use = 0;
-      GO_DISPATCH_LNV(F, { use = try_sddmm_walk<L, NV>(tag, plan, n_src_rows, A, B, y, h, st); });
-      if (use < 0) return -use;
-      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
-      GO_DISPATCH_LNV(F, { use = try_sddmm_sweep<L, NV>(tag, plan, n_src_rows, A, B, y, h, d4, st); });
+      GO_DISPATCH_LNV(F, { use = try_sddmm_sweep<L, NV>(tag, dtype, plan, n_src_rows, A, B, y, h, d4, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
@@ -803,22 +763,30 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
 template <bool EDGE_X>
 int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
                 const i64* indices, const void* w, const void* X, void* out, i64 C, i64 E,
-                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st,
-                const graphop_plan* other = nullptr, i64 n_other_cols = 0) {
+                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
   if (C == 0) return GRAPHOP_OK;
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   if constexpr (!EDGE_X) {
     if (try_spmm_block(tag, dtype, plan, n_src_rows, w, X, out, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+  }
+  // fp64 with a plan: the walk kernel at rows of 256 B - 1 KB (d = 32 / 64 / 128), else the generic kernels
+  if constexpr (!EDGE_X) {
+    if (plan && fast64_ok(dtype, h, d, E, n_src_rows)) {
+      int use = 0;
+      GO_DISPATCH_LNV((int)(2 * d), { use = try_spmm_walk<L, NV>(tag, dtype, plan, n_src_rows, w, X, out, h, 0, st); });
+      if (use < 0) return -use;
+      if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+    }
   }
   if (!EDGE_X && fast_ok(dtype, h, d, E, n_src_rows)) {
     const int cpg = cpg_for(C, tuning().spmm_cpg, (int)(h * d));
     const int F = (int)(h * d), d4 = (int)(d / 4);
     {
       int use = 0;
-      GO_DISPATCH_LNV(F, { use = try_spmm_walk<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, st); });
+      GO_DISPATCH_LNV(F, { use = try_spmm_walk<L, NV>(tag, dtype, plan, n_src_rows, w, X, out, h, d4, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
-      GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, other, n_other_cols, st); });
+      GO_DISPATCH_LNV(F, { use = try_spmm_sweep<L, NV>(tag, plan, n_src_rows, w, X, out, h, d4, st); });
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
@@ -1008,6 +976,7 @@ int softmax_backward_t(const i64* row, const i64* indptr, const i64* eid, const 
 }
 
 inline int check_common(const char* fn, int dtype, i64 C, i64 E, i64 h, i64 d) {
+  GO_TRY(check_async_error());   // a kernel of an earlier launch reported a failure
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: dtype must be GRAPHOP_F32 or "
                "GRAPHOP_F64", fn);
   GO_CHECK_ARG(C >= 0 && E >= 0 && h >= 1 && d >= 0, "%s: negative size (n_chunks=%lld n_edges=%lld "
@@ -1056,15 +1025,13 @@ std::vector<TuneEntry> tune_table() {
       {"sddmm_cpg", &t.sddmm_cpg}, {"spmm_cpg", &t.spmm_cpg}, {"force_generic", &t.force_generic},
       {"sweep", &t.sweep}, {"window_kb", &t.window_kb}, {"mall_window_kb", &t.mall_window_kb}, {"max_windows", &t.max_windows},
       {"sweep_min_kb", &t.sweep_min_kb}, {"sweep_bpc", &t.sweep_bpc}, {"sweep_k", &t.sweep_k},
-      {"vrow_t", &t.vrow_t}, {"sweep_drift", &t.sweep_drift},
-      {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_prefetch", &t.sweep_prefetch},
-      {"sweep_mode", &t.sweep_mode}, {"sweep_w", &t.sweep_w}, {"spmm_window_scale", &t.spmm_window_scale}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
+      {"vrow_t", &t.vrow_t}, {"sweep_min_granule", &t.sweep_min_granule}, {"sweep_w", &t.sweep_w}, {"spmm_window_scale", &t.spmm_window_scale}, {"dense_blocks", &t.dense_blocks}, {"dense_min_fill", &t.dense_min_fill},
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
-      {"transpose_scalars", &t.transpose_scalars}, {"attn_fused", &t.attn_fused},
+      {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
       {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
-      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_steps", &t.walk_steps}};
+      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps}};
 }
 }  // namespace
 
@@ -1104,6 +1071,8 @@ int64_t graphop_memory_bytes(void) {
   std::lock_guard<std::mutex> lk(g_alloc_mu);
   return (int64_t)g_bytes;
 }
+
+int graphop_check_device_errors(void) { return check_async_error(); }
 
 int graphop_tune_reset(void) {
   tuning_mut() = Tuning();   // the defaults (environment overrides included), as at library load
@@ -1218,28 +1187,27 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
                          int fused, void* stream) {
   GO_CHECK_ARG(plan != nullptr && n_table_rows >= 0 && h >= 1 && d >= 0, "plan_prepare: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (!fast_ok(dtype, h, d, plan->info.n_edges, n_table_rows)) return GRAPHOP_OK;   // generic kernels: nothing cached
+  const bool f64 = fast64_ok(dtype, h, d, plan->info.n_edges, n_table_rows);   // fp64: staged SDDMM strip + walk only
+  if (!f64 && !fast_ok(dtype, h, d, plan->info.n_edges, n_table_rows)) return GRAPHOP_OK;   // generic kernels: nothing cached
   int rc = 0;
-  GO_DISPATCH_LNV((int)(h * d), {
+  GO_DISPATCH_LNV((int)(f64 ? 2 * d : h * d), {
     SweepLaunch sl;
     SweepOpts o;
     o.dry_run = 1;
-    o.bpc = sweep_bpc(NV, h == 1, tuning().sweep_mode == 1);
+    o.bpc = f64 ? 3 : sweep_bpc(NV, h == 1);
     o.staged = sddmm_staged(plan, L, NV, h, n_table_rows);
     o.stage_lds_per_group = StageCfg<L, 1>::kLdsIntsPerGroup * (int)sizeof(int) + (h > 1 ? 64 * (int)h : 0);
-    rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/false, &o);
+    if (!f64 || (o.staged && NV == 1 && L >= 16))
+      rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, /*accumulating=*/false, &o);
     o.staged = spmm_staged(L, NV, h, n_table_rows);
-    if (rc >= 0) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, 0, /*accumulating=*/true, &o);
+    if (rc >= 0 && !f64) rc = choose_sweep(plan, n_table_rows, L, NV, st, &sl, /*accumulating=*/true, &o);
     // walk layouts of the passes that would take them (kernels_walk.h)
     if constexpr (NV == 1 && L >= 16) {
       WalkLaunch wl;
       const int bit = plan->info.eid_identity ? 2 : 4;
-      if (rc >= 0 && spmm_walk_k<L, NV>(h) > 0 && (tuning().walk & bit)) {
-        const int r2 = choose_walk<L, NV>(plan, n_table_rows, 1, spmm_walk_k<L, NV>(h), kWalkWorkers, 1, st, &wl, /*dry_run=*/true);
-        if (r2 < 0) rc = r2;
-      }
-      if (rc >= 0 && h == 1 && (tuning().walk & 1)) {
-        const int r2 = choose_walk<L, NV>(plan, n_table_rows, kWave / L, kWalkK, kFastBlock, kWalkBpc, st, &wl, /*dry_run=*/true);
+      const int K = spmm_walk_k<L, NV>(h, dtype);
+      if (rc >= 0 && K > 0 && (tuning().walk & bit) && (h == 1 || table_off32(n_table_rows, L, NV))) {
+        const int r2 = choose_walk<L, NV>(plan, n_table_rows, K, st, &wl, /*dry_run=*/true);
         if (r2 < 0) rc = r2;
       }
     }
@@ -1357,8 +1325,6 @@ void graphop_plan_destroy(graphop_plan_t* plan) {
   if (plan->idx32) go_free(plan->idx32);
   if (plan->eid32) go_free(plan->eid32);
   if (plan->long_segs) go_free(plan->long_segs);
-  if (plan->inv32) go_free(plan->inv32);
-  if (plan->scalar_scratch) go_free(plan->scalar_scratch);
   if (plan->blk_seg) go_free(plan->blk_seg);
   if (plan->seg_e0) go_free(plan->seg_e0);
   if (plan->seg_row) go_free(plan->seg_row);
@@ -1434,10 +1400,7 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   if (n_col_chunks > 0) {
     GO_PTR(fn, col); GO_PTR(fn, indptr_c); GO_PTR(fn, eid_c); GO_PTR(fn, indices_c); GO_PTR(fn, A); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dB", dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
-                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st,
-                              plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr_r,
-                                                (const i64*)eid_r, (const i64*)indices_r,
-                                                n_row_chunks, n_edges) ? plan_r : nullptr, n_b));
+                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st));
   }
   return GRAPHOP_OK;
 }
@@ -1550,10 +1513,7 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     GO_PTR(fn, col); GO_PTR(fn, indptr_t); GO_PTR(fn, eid_t); GO_PTR(fn, indices_t); GO_PTR(fn, edata); GO_PTR(fn, dy);
     // kernel_1: dx = SpMM(edata, dy) over the column-major CSR, all C' chunks (:151-163)
     GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
-                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st,
-                              plan_matches_full(plan_r, (const i64*)row, (const i64*)indptr,
-                                                (const i64*)eid, (const i64*)indices, n_row_chunks,
-                                                n_edges) ? plan_r : nullptr, n_x));
+                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st));
   }
   return GRAPHOP_OK;
 }

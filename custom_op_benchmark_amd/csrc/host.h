@@ -27,17 +27,12 @@ struct Tuning {
   int sweep_bpc;        // resident blocks per CU for the sweep drivers (3: with staged ids 2 % faster than the 4 the kernels are compiled for)
   int sweep_k;          // vrows per lane group (0 = auto)
   int vrow_t;           // vrow length cap (0 = auto from the mean row length)
-  int sweep_drift;      // windows a wave may run ahead of the slowest one (0 = free-running)
   int sweep_min_granule;  // mean slots per (row, window) below which the sweep is not worth it
-  int sweep_prefetch;     // touch the next window at the start of every step
   int dense_blocks;       // use the fp32-MFMA block-dense drivers when the plan found a cover
   int dense_min_fill;     // ... whose 32x32 tiles hold at least this many percent edges
   int dense_detect_min_fill;  // plan creation keeps a block cover only above this fill (percent)
   int sweep_w;            // > 0: number of column windows (overrides window_kb)
   int spmm_window_scale;  // window-owner SpMM over identity-eid slots: windows this many times window_kb
-  int sweep_mode;         // 0: workgroups own vrows and walk the windows in step (paced sweep);
-                          // 1: XCDs own windows, waves pull (window, vrow tile) tasks (window-owner)
-  int transpose_scalars;  // column-major passes: transpose the per-slot scalars first (h == 1)
   int attn_fused;         // attention_forward/backward: use the fused window kernels when they apply
   int attn_window_scale;  // fused kernels gather 2 packed rows per slot: windows of this many times window_kb
   int attn_k;             // vrows per lane group in the fused kernels (0 = auto)
@@ -48,8 +43,9 @@ struct Tuning {
                           // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
   int touch_sddmm;        // SDDMM strips: per-task id-line touches (kernels_fast.h: LineTouch): bit 0 ids, bit 1 edge ids
-  int walk;               // walk drivers (kernels_walk.h): bit 0 SDDMM-type passes, bit 1 SpMM-type over identity-eid
-                          // (row-major) slots, bit 2 SpMM-type over permuted (column-major) slots
+  int walk;               // walk drivers (kernels_walk.h): bit 1 SpMM-type passes over identity-eid (row-major) slots,
+                          // bit 2 SpMM-type over permuted (column-major) slots (bit 0 was the SDDMM-type walk kernel of
+                          // round 3: 1.63-1.73 ms against 1.51 on the window-owner strips, removed in round 4)
   int walk_window_kb;     // bytes of gathered table per window of the walk drivers, passes over identity-eid (row-major) slots
   int walk_window_kb_col; // ... passes over permuted (column-major) slots: their per-slot scalars are a gather whose lines
                           // share the L2 with the window (Reddit shape: 2.72 ms at 4 MB, 2.25 at 2 MB; row-major 1.71 / 1.78)
@@ -57,6 +53,7 @@ struct Tuning {
   int walk_steps;         // pacing steps per column window
   int walk_min_bin;       // fewest slots per (lane group, round) bin for the walk drivers to be chosen
   int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
+  int walk_fault;         // tests only: inject a hand-over fault into the walk kernel (kernels_walk.h: WalkView::fault)
   int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
   int n_cu;
   Tuning() {
@@ -68,11 +65,7 @@ struct Tuning {
     sweep_bpc = env_int("GRAPHOP_SWEEP_BPC", 3);
     sweep_k = env_int("GRAPHOP_SWEEP_K", 0);
     vrow_t = env_int("GRAPHOP_VROW_T", 0);
-    sweep_drift = env_int("GRAPHOP_SWEEP_DRIFT", 2);
     sweep_min_granule = env_int("GRAPHOP_SWEEP_MIN_GRANULE", 4);
-    transpose_scalars = env_int("GRAPHOP_TRANSPOSE_SCALARS", 0);   // measured: the scatter costs 1.3 ms, saves 0.85
-    sweep_prefetch = env_int("GRAPHOP_SWEEP_PREFETCH", 0);   // measured: no gain on Reddit-shape
-    sweep_mode = env_int("GRAPHOP_SWEEP_MODE", 1);
     sweep_w = env_int("GRAPHOP_SWEEP_W", 0);
     spmm_window_scale = env_int("GRAPHOP_SPMM_WINDOW_SCALE", 2);
     dense_blocks = env_int("GRAPHOP_DENSE_BLOCKS", 1);
@@ -86,7 +79,7 @@ struct Tuning {
     attn_max_d = env_int("GRAPHOP_ATTN_MAX_D", 64);
     staged_ids = env_int("GRAPHOP_STAGED_IDS", 7);
     touch_sddmm = env_int("GRAPHOP_TOUCH_SDDMM", 1);
-    walk = env_int("GRAPHOP_WALK", 6);   // SDDMM-type passes: the window-owner drivers measure 1.55-1.6 ms against 1.63-1.73
+    walk = env_int("GRAPHOP_WALK", 6);
     walk_window_kb = env_int("GRAPHOP_WALK_WINDOW_KB", 4096);
     walk_window_kb_col = env_int("GRAPHOP_WALK_WINDOW_KB_COL", 2048);
     walk_drift = env_int("GRAPHOP_WALK_DRIFT", 3);
@@ -94,6 +87,7 @@ struct Tuning {
     walk_min_bin = env_int("GRAPHOP_WALK_MIN_BIN", 1024);
     walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);
+    walk_fault = 0;
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -124,7 +118,6 @@ struct SweepLaunch {
   SweepView view;
   unsigned blocks;
   size_t lds_bytes;
-  bool window_owner;
 };
 
 // Overrides for kernels whose gathered rows / per-vrow LDS rows are not one F-float row
@@ -134,7 +127,6 @@ struct SweepOpts {
   int K = 0;              // vrows per lane group (0 = auto)
   int window_scale = 0;   // > 0: windows of this many times window_kb, vrows as many times longer
   int bpc = 0;            // resident workgroups per CU (0 = tuning().sweep_bpc)
-  int require_owner = 0;  // 1: only the window-owner order is acceptable (return 0 otherwise)
   int dry_run = 0;        // 1: decide and build the cached structure only (no task queue is taken)
   int touch = 0;          // SweepView::touch of the launch
   int staged = 0;         // 1: also fetch / build the dealt (window-major) layout and put it in the view
@@ -144,8 +136,7 @@ struct SweepOpts {
 // Decide whether the window-sweep driver applies and fetch / build its structure.
 // Returns 1 = use sweep, 0 = use the chunk driver, <0 = error code (negated).
 int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
-                 SweepLaunch* out, int force_windows = 0, bool accumulating = false,
-                 const SweepOpts* opts = nullptr);
+                 SweepLaunch* out, bool accumulating = false, const SweepOpts* opts = nullptr);
 
 int plan_n_sweeps(const graphop_plan* p);
 const Sweep* plan_sweep_at(const graphop_plan* p, int i);

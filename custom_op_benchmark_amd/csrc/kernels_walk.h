@@ -16,11 +16,10 @@
 // no per-window round-up, no dealing.  Where a bin stands in the table after a given share of its
 // slots varies from bin to bin like 1 / sqrt(slots per bin) (which windows a row's neighbours fall
 // into is random); that spread is what the L2 has to hold.
-// `GW` of the layout = lane groups that share one bin: 1 for the SpMM-type kernel (the rows are the lane
-// group's own: partial sums are folded into LDS with a plain, deferred read-modify-write); the lane
-// groups of a wave for the SDDMM-type kernel, which only reads the rows (half the spread: 1.76 ->
-// 1.66 ms on the Reddit shape; SpMM-type passes would have to order the updates of rows cut between
-// two groups: 1.78 -> 2.03 ms).
+// The layout is cut with bins per LANE GROUP: the rows are the lane group's own, partial sums are folded into LDS with
+// a plain, deferred read-modify-write.  (Round 3 also had an SDDMM-type walk kernel with bins per wave, A rows in LDS
+// for the round: 1.63-1.73 ms per pass against 1.51 on the window-owner strips, which have no flush to save; removed
+// in round 4, numbers in profiles/r3_walk_experiments.txt.)
 #pragma once
 #include "kernels_fast.h"
 
@@ -40,10 +39,30 @@ struct WalkView {
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
   int stream_weights;    // 1: the per-slot weights are read in storage order (identity eid): nontemporal loads
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
+  int* err;              // host-visible error word (host.h: device_error_word): a hand-over that timed out stores its code here
+  int fault;             // fault injection (knob walk_fault, tests only): 1 = the feeders never deliver chunk 1 of lane group 0,
+                         // 2 = quad 0 never reports step 0 finished
 };
 
+// Hand-overs inside a walk workgroup (worker <-> feeder rings, quad steps) are CORRECTNESS-critical: a worker that
+// read a ring chunk the feeder has not written, or started a unit before its quad's previous step was folded into
+// LDS, would produce wrong numbers.  Their spins are bounded only so that a launch cannot hang the device; when a
+// bound expires the wave stores a code in the host-visible error word, raises the workgroup's abort flag (every
+// spin of the kernel polls it) and leaves.  The outputs of such a launch are garbage and the host reports
+// GRAPHOP_ERR_HIP at the next library call / graphop_check_device_errors (graphop_hip.hip: check_async_error).
+// The XCD pacer is different: results never depend on it, it gives up silently.
+constexpr int kWalkErrQuad = 1;     // a (step, quad) unit waited for the quad's previous step
+constexpr int kWalkErrRing = 2;     // a worker waited for a ring chunk of its feeder
+constexpr int kWalkErrFeeder = 3;   // a feeder waited for ring space
+constexpr int kWalkSpinQuad = 1 << 24;    // x s_sleep(1): ~1 s
+constexpr int kWalkSpinRing = 1 << 22;    // x s_sleep(1): ~0.25 s
+constexpr int kWalkSpinFeeder = 1 << 23;  // x s_sleep(4): ~2 s
+__device__ __forceinline__ void walk_fail(int* err, int* wg_abort, int code) {
+  __hip_atomic_store(wg_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr int kWalkIdMask = (1 << kWalkKShift) - 1;
-constexpr int kWalkBpc = 2;   // resident workgroups per CU the walk kernels are sized for (LDS)
 
 // Soft pacing between the waves of one walk launch, per XCD (counters sharded by the hardware XCC id,
 // layout as SweepPacer: sync[xcc * 64] = workgroups registered, then per (XCD, step) an arrival
@@ -74,28 +93,6 @@ struct WalkPacer {
     if (threadIdx.x < 12) lds[threadIdx.x] = 0;
     if (threadIdx.x == 0) __hip_atomic_fetch_add(reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-  }
-  // every lane group of this wave has left all steps < upto (wave-uniform call, all lanes).  Each wave
-  // keeps its own progress word in LDS; whoever raises the workgroup's minimum forwards the newly
-  // finished steps to the XCD counters (an LDS atomic max hands every step to exactly one wave).
-  __device__ __forceinline__ void signal_upto(int upto) {
-    if (upto <= done_next) return;
-    done_next = upto;
-    if (active && (threadIdx.x & (kWave - 1)) == 0) {
-      __hip_atomic_store(lds + (threadIdx.x >> 6), upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      int m = upto;
-      for (int w = 0; w < n_waves; ++w) {
-        const int o = __hip_atomic_load(lds + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        m = o < m ? o : m;
-      }
-      const int from = __hip_atomic_fetch_max(lds + 8, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      for (int st = from; st < m; ++st) {
-        int* c = ctr + (i64)st * 2 * kSyncStride;
-        const int prev = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int n = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1 >= n) __hip_atomic_store(c + kSyncStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
   // progress slot `slot` (a quad of the ticketed walk kernel; n_waves = number of slots) has finished all steps < upto
   __device__ __forceinline__ void signal_slot(int slot, int upto) {
@@ -145,15 +142,6 @@ struct WalkPacer {
   }
 };
 
-template <int L, int SH>
-__device__ __forceinline__ i64 walk_bin_index(const WalkView& s, int r) {   // bin of this lane group's sharing set in round r
-  constexpr int SPB = kFastBlock / (L * SH);                // sharing sets per workgroup
-  const int slots = s.xcd_slots;
-  const i64 x = blockIdx.x % slots, i = blockIdx.x / slots;
-  const i64 per_slot = (s.groups / SH) / slots;             // sharing sets per XCD slot
-  return ((i64)r * slots + x) * per_slot + i * SPB + threadIdx.x / (L * SH);
-}
-
 template <int GPB>
 __device__ __forceinline__ i64 walk_bin_index_of(const WalkView& s, int r, int g_in_blk) {   // bins per lane group
   const int slots = s.xcd_slots;
@@ -172,12 +160,6 @@ __device__ __forceinline__ int wave_max_int(int v) {   // v group-uniform
     m = o > m ? o : m;
   }
   return m;
-}
-
-// LDS of one workgroup: [lane groups][kWalkK] rows of 16*L*NV bytes, then the id rings.
-template <int L, int NV>
-__host__ __device__ constexpr size_t walk_lds_bytes() {
-  return (size_t)(kFastBlock / L) * ((size_t)kWalkK * L * NV * 16 + (size_t)StageCfg<L, 2>::kLdsIntsPerGroup * 4);
 }
 
 // ---- SpMM-type walk kernel: eight worker waves + four FEEDER waves per workgroup --------------------------
@@ -203,14 +185,15 @@ constexpr int kFeeders = 4;        // feeder waves, each serving GPB / kFeeders 
 constexpr int kWalkThreads = kWalkWorkers + kFeeders * kWave;
 
 // LDS of the SpMM-type walk kernel: per lane group K rows + a ring of (id, HV per-head weights) per slot
+// (WS = 32-bit words per weight: 1 for fp32, 2 for fp64)
 template <int L, int NV>
-__host__ __device__ constexpr size_t spmm_walk_lds_bytes(int K, int HV) {
-  return (size_t)(kWalkWorkers / L) * ((size_t)K * L * NV * 16 + (size_t)kFeedChunk * kFeedRing * 4 * (1 + HV));
+__host__ __device__ constexpr size_t spmm_walk_lds_bytes(int K, int HV, int WS = 1) {
+  return (size_t)(kWalkWorkers / L) * ((size_t)K * L * NV * 16 + (size_t)kFeedChunk * kFeedRing * 4 * (1 + HV * WS));
 }
 // most rows per lane group that fit next to the rings (one workgroup per CU, 2 KB left to the static words)
 template <int L, int NV>
-__host__ __device__ constexpr int spmm_walk_rows(int HV) {
-  const long long per_group = (160LL * 1024 - 2048) / (kWalkWorkers / L) - (long long)kFeedChunk * kFeedRing * 4 * (1 + HV);
+__host__ __device__ constexpr int spmm_walk_rows(int HV, int WS = 1) {
+  const long long per_group = (160LL * 1024 - 2048) / (kWalkWorkers / L) - (long long)kFeedChunk * kFeedRing * 4 * (1 + HV * WS);
   const long long k = per_group / ((long long)L * NV * 16);
   return (int)(k > kWalkK ? kWalkK : (k < 0 ? 0 : k));
 }
@@ -232,16 +215,23 @@ __device__ __forceinline__ void lds_st(int* p, int v) {
 // Bins per lane group (SH = 1): the LDS rows are the group's own.  HV = heads (a row is HV x d floats, d4 = d / 4
 // float4s per head; w holds HV scalars per edge): the feeder stages all HV weights of a slot, a worker
 // lane reads its head's.
-template <int L, int NV, int HV>
-__global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second bound: waves per SIMD)
-    WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out, int d4) {
-  extern __shared__ float4 lds[];
+// T = float or double (a row is 16 * L * NV bytes either way; several heads: fp32 only); OFF32 = false: tables of
+// 4 GiB and more (the row offset is a 64-bit multiply-add per request instead of a 32-bit vector offset).
+template <int L, int NV, int HV, typename T, bool OFF32>
+__device__ __forceinline__ void spmm_walk_body(
+    const WalkView& s, const T* __restrict__ wgt, const T* __restrict__ X, T* __restrict__ out, int d4) {
+  using TR = RowT<T>;
+  using vec = typename TR::vec;
+  extern __shared__ float4 lds_raw[];
+  vec* lds = reinterpret_cast<vec*>(lds_raw);
   constexpr int GPB = kWalkWorkers / L;
   constexpr i64 F4 = (i64)L * NV;
   constexpr int SB = StripCfg<L, NV>::SB;
   constexpr int RING = kFeedChunk * kFeedRing;
-  constexpr int RSTRIDE = RING * (1 + HV);           // ints per lane group's ring: ids, then HV weights per slot
+  constexpr int WS = TR::WORDS;                      // 32-bit words per weight
+  constexpr int RSTRIDE = RING * (1 + HV * WS);      // ints per lane group's ring: ids, then HV weights per slot
   constexpr bool H1 = HV == 1;
+  static_assert(sizeof(T) == 4 || HV == 1, "several heads: fp32 only");
   static_assert(L >= 16 && kWalkK <= L && SB == 16 && kFeedChunk % SB == 0, "lane k of a group holds the bin's k-th row");
   static_assert(HV == 1 || HV == 2 || HV == 4 || HV == 8, "heads");
   const int K = s.K;
@@ -251,6 +241,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
   constexpr int GW = kWave / L, NQ = GPB / GW;      // lane groups per wave; quads (see the worker waves) per workgroup
   static_assert(NQ <= 8, "pacer progress words");
   __shared__ int tk_next, quad_done[NQ], quad_len[NQ], bin_total[GPB], bin_seg[GPB];
+  __shared__ int wg_abort;           // raised by walk_fail: every wave of the workgroup leaves
+  if (threadIdx.x == 0) wg_abort = 0;
   if (threadIdx.x < GPB) { feed_ready[threadIdx.x] = 0; feed_done[threadIdx.x] = 0; bin_total[threadIdx.x] = 0; bin_seg[threadIdx.x] = 0; }
   if (threadIdx.x < NQ) { quad_done[threadIdx.x] = 0; quad_len[threadIdx.x] = SB; }
   if (threadIdx.x == 0) tk_next = 0;
@@ -276,12 +268,13 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     long long t_space = 0;
     // identity-eid slots read every weight line once, a run at a time: streamed past the caches; permuted slots
     // share their lines with the neighbouring columns' lane groups of the same XCD: cached
-    auto ld_w = [&](int wi, float (&o)[HV]) {
+    auto ld_w = [&](int wi, T (&o)[HV]) {
       if (wi < 0) {
 #pragma unroll
-        for (int i = 0; i < HV; ++i) o[i] = 0.f;
+        for (int i = 0; i < HV; ++i) o[i] = 0;
       } else if constexpr (HV == 1) {
         o[0] = s.stream_weights ? __builtin_nontemporal_load(wgt + wi) : wgt[wi];
+      } else if constexpr (sizeof(T) != 4) {
       } else if constexpr (HV == 2) {
         const walk_f2* q = reinterpret_cast<const walk_f2*>(wgt) + wi;
         const walk_f2 t = s.stream_weights ? __builtin_nontemporal_load(q) : *q;
@@ -298,7 +291,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     for (int r = 0; r < s.rounds; ++r) {
       int pos0[NG], total[NG], nchunk[NG], c[NG];
       int idW[NG], idA[NG], wiA[NG], wi0[NG];
-      float wvW[NG][HV];
+      T wvW[NG][HV];
       auto load_pair = [&](int g, int ck, int& idw, int& wi) {
         idw = 0; wi = -1;
         if (ck * kFeedChunk < total[g]) {
@@ -308,7 +301,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
           if (j < total[g]) wi = __builtin_nontemporal_load(s.widx + pos0[g] + jc);
         }
       };
-      int left = 0;
+      int left = 0, idle = 0;
       {
         int p_l = 0, t_l = 0;                         // lane g < NG: run start / length of lane group g0 + g
         if (h < NG) {
@@ -342,12 +335,16 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
           if (c[g] >= nchunk[g]) continue;                                // wave-uniform
           const int gc = chunk_base[g] + c[g];                            // running chunk number of this lane group
           if (gc - __builtin_amdgcn_readlane(done_l, g) >= kFeedRing) continue;   // ring full: the group is still reading
+          if (s.fault == 1 && g0 + g == 0 && gc >= 1) continue;                   // (injected fault: chunk 1 of lane group 0 never comes)
           adv |= 1u << g;
           int* ring = ring_base + (g0 + g) * RSTRIDE;
           const int at = (gc % kFeedRing) * kFeedChunk + h;
           ring[at] = idW[g];
-          if constexpr (HV == 1) {
+          if constexpr (HV == 1 && sizeof(T) == 4) {
             ring[RING + at] = __float_as_int(wvW[g][0]);
+          } else if constexpr (HV == 1) {
+            *reinterpret_cast<T*>(ring + RING + at * WS) = wvW[g][0];
+          } else if constexpr (sizeof(T) != 4) {
           } else if constexpr (HV == 2) {
             *reinterpret_cast<float2*>(ring + RING + at * 2) = make_float2(wvW[g][0], wvW[g][1]);
           } else {
@@ -362,8 +359,11 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
           const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
           __builtin_amdgcn_s_sleep(4);
           if (s.dbg) t_space += __builtin_amdgcn_s_memtime() - t0;
+          if (lds_ld(&wg_abort)) return;
+          if (++idle > kWalkSpinFeeder) { walk_fail(s.err, &wg_abort, kWalkErrFeeder); return; }
           continue;
         }
+        idle = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           if (!((adv >> g) & 1)) continue;
@@ -410,17 +410,20 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
     if (gstep >= n_steps) break;
     const int r = gstep / s.steps, sidx = gstep - r * s.steps;
     {
-      int it = 0;
+      int it = 0;                                     // (wave-uniform loop: every lane polls the same words)
+      bool dead = false;
       const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
       while (lds_ld(quad_done + q) < gstep) {         // the quad's previous step is still being worked on
         __builtin_amdgcn_s_sleep(1);
-        if (++it > (1 << 24)) break;                  // (never observed; bounds the spin)
+        if (lds_ld(&wg_abort)) { dead = true; break; }
+        if (++it > kWalkSpinQuad) { walk_fail(s.err, &wg_abort, kWalkErrQuad); dead = true; break; }
       }
       if (s.dbg) pacer.t_feed += __builtin_amdgcn_s_memtime() - t0;
+      if (dead) break;                                // never start a unit on a state that is not there
     }
     pacer.wait_enter(gstep, gstep);
     const int bin = q * GW + gq;
-    float4* accs = lds + (i64)bin * K * F4;           // [K][NV][L]
+    vec* accs = lds + (i64)bin * K * F4;              // [K][NV][L]
     const int* ring = ring_base + bin * RSTRIDE;
     const i64 tb = walk_bin_index_of<GPB>(s, r, bin);
     int total, step_len;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       total = s.bin_cum[tb];
       for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < NV; ++v) accs[(k * NV + v) * L + l] = TR::zero();
       const int quad_total = wave_max_int<L>(total);
       // pacing steps = equal shares of the quad's longest run: equal positions in the runs mean nearly equal columns
       step_len = (((quad_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB;
@@ -446,9 +449,9 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       const int quad_total = wave_max_int<L>(total);
       j1 = j1 < quad_total ? j1 : quad_total;
     }
-    float4 acc[NV], pend_acc[NV], pend_rd[NV];
+    vec acc[NV], pend_acc[NV], pend_rd[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < NV; ++v) acc[v] = pend_acc[v] = pend_rd[v] = TR::zero();
     int k_cur = -1, pend_k = -1;
     // Row change: the partial sum of the row just left is folded into its LDS row by a DEFERRED
     // read-modify-write -- the LDS row is requested now, added and written back at the NEXT row
@@ -458,8 +461,8 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
       if (pend_k >= 0) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          float4 o = pend_rd[v];
-          o.x += pend_acc[v].x; o.y += pend_acc[v].y; o.z += pend_acc[v].z; o.w += pend_acc[v].w;
+          vec o = pend_rd[v];
+          TR::add(o, pend_acc[v]);
           accs[(pend_k * NV + v) * L + l] = o;
         }
       }
@@ -472,34 +475,30 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         for (int v = 0; v < NV; ++v) {
           pend_acc[v] = acc[v];
           pend_rd[v] = accs[(k_cur * NV + v) * L + l];
-          acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[v] = TR::zero();
         }
       }
       k_cur = kt;
     };
-    struct Meta { int k; float w; };
-    auto consume = [&](const float4 (&x)[SB][NV], const Meta& m, const float (&wv)[H1 ? 1 : SB]) {
+    struct Meta { int k; T w; };
+    auto consume = [&](const vec (&x)[SB][NV], const Meta& m, const T (&wv)[H1 ? 1 : SB]) {
       static_for<SB>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         const int kt = group_bcast<L, u>(m.k);
         if (__builtin_expect(kt != k_cur, 0)) row_change(kt);   // group-uniform; about once per batch
-        float w1;
+        T w1;
         if constexpr (H1) w1 = group_bcast<L, u>(m.w);
         else w1 = wv[u];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          acc[v].x = fmaf(w1, x[u][v].x, acc[v].x);
-          acc[v].y = fmaf(w1, x[u][v].y, acc[v].y);
-          acc[v].z = fmaf(w1, x[u][v].z, acc[v].z);
-          acc[v].w = fmaf(w1, x[u][v].w, acc[v].w);
-        }
+        for (int v = 0; v < NV; ++v) TR::fma(acc[v], w1, x[u][v]);
       });
     };
     // one batch of rows in flight per lane group; id and weight of the next batch come from the feeder's ring
-    float4 x[SB][NV];
+    vec x[SB][NV];
     Meta mc, mn;
-    mc.k = mn.k = 0; mc.w = mn.w = 0.f;
-    unsigned off_c = 0, off_n = 0;
+    mc.k = mn.k = 0; mc.w = mn.w = 0;
+    unsigned off_c = 0, off_n = 0;                    // OFF32: byte offset of the neighbour's row; else its row number
+    int ring_failed = 0;                              // per lane group; made wave-uniform after every stage() call
     auto stage = [&](int jb, Meta& m, unsigned& off) {
       if ((jb % kFeedChunk) == 0) {                   // entering a chunk: earlier ones are read, this one must be there
         const int gs = seg_base + jb / kFeedChunk;
@@ -507,40 +506,48 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         int it = 0;
         while (lds_ld(feed_ready + bin) <= gs) {
           __builtin_amdgcn_s_sleep(1);
-          if (++it > (1 << 22)) break;                // (never observed; bounds the spin)
+          if (lds_ld(&wg_abort)) { ring_failed = 1; break; }
+          if (++it > kWalkSpinRing) { walk_fail(s.err, &wg_abort, kWalkErrRing); ring_failed = 1; break; }
         }
       }
       const int at = (seg_base * kFeedChunk + jb + l) % RING;
       const int idw = ring[at];
       m.k = (int)((unsigned)idw >> kWalkKShift);
-      off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
-      if constexpr (H1) m.w = __int_as_float(ring[RING + at]);
+      off = OFF32 ? (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16) : (unsigned)(idw & kWalkIdMask);
+      if constexpr (H1 && sizeof(T) == 4) m.w = __int_as_float(ring[RING + at]);
+      else if constexpr (H1) m.w = *reinterpret_cast<const T*>(ring + RING + at * WS);
     };
     if (j0 < total && j0 < j1) stage(j0, mc, off_c);
-    for (int jb = j0; jb < j1; jb += SB) {
+    bool dead = __any(ring_failed) != 0;
+    for (int jb = j0; jb < j1 && !dead; jb += SB) {
       if (jb < total) {
         static_for<SB>([&](auto uc) {
           constexpr int u = decltype(uc)::value;
           const unsigned o = group_bcast<L, u>(off_c);
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[u][v] = ld4_off(X, o + (unsigned)((v * L + l) * 16));
+          for (int v = 0; v < NV; ++v) {
+            if constexpr (OFF32) x[u][v] = ld16_off<T>(X, o + (unsigned)((v * L + l) * 16));
+            else x[u][v] = ld16_row64<T>(X, o, (unsigned)(F4 * 16), (unsigned)((v * L + l) * 16));
+          }
         });
-        float wv[H1 ? 1 : SB];
+        T wv[H1 ? 1 : SB];
         if constexpr (!H1) {
           // this batch's weights of the lane's head -- read BEFORE the next batch is staged: entering a new chunk
           // there hands this batch's chunk back to the feeder (LDS operations of a wave execute in order)
           const int b0 = (seg_base * kFeedChunk + jb) % RING;    // a batch never wraps (RING % SB == 0)
 #pragma unroll
-          for (int u = 0; u < SB; ++u) wv[u] = __int_as_float(ring[RING + (b0 + u) * HV + head]);
+          for (int u = 0; u < SB; ++u) wv[u] = (T)__int_as_float(ring[RING + (b0 + u) * HV + head]);
           asm volatile("" ::: "memory");
         } else {
-          wv[0] = 0.f;
+          wv[0] = 0;
         }
         if (jb + SB < total && jb + SB < j1) stage(jb + SB, mn, off_n);
         consume(x, mc, wv);
         mc = mn; off_c = off_n;
       }
+      if (((jb + SB) % kFeedChunk) == 0) dead = __any(ring_failed) != 0;   // a chunk that never came: leave before its ids are used
     }
+    if (dead) break;
     row_change(-1);      // the last row becomes the pending one ...
     finish_pending();    // ... and is folded in: the bin's state is in LDS again
     if (sidx == s.steps - 1) {
@@ -554,108 +561,34 @@ __global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second
         const int rec = __shfl(my_row, k, L);
         if (rec == -1) continue;   // group-uniform
         const i64 row = rec & 0x7fffffff;
-        float4 a[NV];
+        vec a[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) a[v] = accs[(k * NV + v) * L + l];
         if (rec < 0) {
-          atomic_flush_dense<L, NV>(out, row, a, l);
+          atomic_flush_dense_t<L, NV, T>(out, row, a, l);
         } else {
 #pragma unroll
-          for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[row * F4 + v * L + l] = a[v];
+          for (int v = 0; v < NV; ++v) reinterpret_cast<vec*>(out)[row * F4 + v * L + l] = a[v];
         }
       }
     }
     // this quad has finished the step (LDS operations of a wave execute in order: the state above is visible first)
-    if ((threadIdx.x & (kWave - 1)) == 0) lds_st(quad_done + q, gstep + 1);
+    if ((threadIdx.x & (kWave - 1)) == 0 && !(s.fault == 2 && q == 0 && gstep == 0)) lds_st(quad_done + q, gstep + 1);
     pacer.signal_slot(q, gstep + 1);
   }
   pacer.report(s.dbg, t_start);
 }
 
-// y[edge] = <A[row], B[neighbour]>   (graphop_kernel.cu:40-55, :135-149); h == 1
-// Bins per wave (SH = lane groups of a wave): the A rows in LDS are only read.
-template <int L, int NV>
-__global__ __launch_bounds__(kFastBlock, kWalkBpc) void k_sddmm_walk_f32(
-    WalkView s, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ y) {
-  extern __shared__ float4 lds[];
-  constexpr int GPB = kFastBlock / L, GW = kWave / L, KW = kWalkK * GW;
-  constexpr i64 F4 = (i64)L * NV;
-  constexpr int SB = StripCfg<L, NV>::SB;
-  static_assert(L >= 16 && KW <= kWave && KW <= (1 << (32 - kWalkKShift)), "lane k of a wave holds the bin's k-th row");
-  const int l = threadIdx.x % L;
-  const int g_in_blk = threadIdx.x / L;
-  const int gq = g_in_blk % GW;
-  const int lw = threadIdx.x & (kWave - 1);
-  float4* rowsA = lds + (i64)(threadIdx.x >> 6) * KW * F4;   // [KW][NV][L], shared by the wave's lane groups
-  int* idbuf = reinterpret_cast<int*>(lds + (i64)GPB * kWalkK * F4) + g_in_blk * StageCfg<L, 2>::kLdsIntsPerGroup;
-  __shared__ int pace_words[16];
-  const long long t_start = __builtin_amdgcn_s_memtime();
-  WalkPacer pacer(s, pace_words);
-  const char* lds_l = reinterpret_cast<const char*>(rowsA) + l * 16;
-  for (int r = 0; r < s.rounds; ++r) {
-    const i64 tb = walk_bin_index<L, GW>(s, r);
-    const i64 gb = tb * GW + gq;
-    const int pos0 = s.bin_pos[gb];
-    const int total = s.bin_cum[gb];
-    const int my_row = lw < KW ? s.bin_rows[tb * KW + lw] : -1;
-    int next_step_at = 0;
-    const int wave_total = wave_max_int<L>(total);
-    // pacing steps = equal shares of this wave's longest run: equal positions in the runs mean nearly equal columns
-    const int step_len = (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB > 0 ? (((wave_total + s.steps - 1) / s.steps + SB - 1) / SB) * SB : SB;
-    IdStage<L, 2> ids;
-    if (total > 0) ids.init(s.ids, s.widx, pos0, idbuf, l, total);
-    for (int k = gq; k < KW; k += GW) {   // A rows of the bin -> LDS (behind the first id segment's request)
-      const int rec = __shfl(my_row, k);
-      if (rec == -1) continue;
-      const i64 row = rec & 0x7fffffff;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) rowsA[(k * NV + v) * L + l] = ld4(A, row * F4 + v * L + l);
-    }
-    float prev_res = 0.f;
-    int prev_e = -1;
-    for (int jb = 0; jb < wave_total; jb += SB) {
-      if (jb >= next_step_at) {   // wave-uniform
-        const int step = r * s.steps + jb / step_len;
-        pacer.signal_upto(step);
-        pacer.wait_enter(step, step);
-        next_step_at = (jb / step_len + 1) * step_len;
-      }
-      if (jb < total) {
-        const int nb = (total - jb) < SB ? (total - jb) : SB;
-        ids.advance(jb);
-        const int j = (jb + l) < total ? jb + l : total - 1;   // lanes past the end re-read the last slot
-        const int idw = ids.id(j);
-        const int my_e = (l < nb) ? ids.eid(j) : -1;
-        const unsigned my_koff = ((unsigned)idw >> kWalkKShift) * (unsigned)(F4 * 16);
-        const unsigned my_off = (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16);
-        float4 b[SB][NV];
-        static_for<SB>([&](auto uc) {
-          constexpr int u = decltype(uc)::value;
-          const unsigned o = group_bcast<L, u>(my_off);
-#pragma unroll
-          for (int v = 0; v < NV; ++v) b[u][v] = ld4_off(B, o + (unsigned)((v * L + l) * 16));
-        });
-        if (prev_e >= 0) y[prev_e] = prev_res;   // behind the row requests (vmcnt retires in order)
-        float part[SB];
-        static_for<SB>([&](auto uc) {
-          constexpr int u = decltype(uc)::value;
-          const unsigned ko = group_bcast<L, u>(my_koff);
-          float4 av[NV];
-#pragma unroll
-          for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(lds_l + ko + v * L * 16);
-          float p = dot4(av[0], b[u][0]);
-#pragma unroll
-          for (int v = 1; v < NV; ++v) p += dot4(av[v], b[u][v]);
-          part[u] = p;
-        });
-        prev_res = group_dots_to_owner<L, SB>(part, l);
-        prev_e = my_e;
-      }
-    }
-    if (prev_e >= 0) y[prev_e] = prev_res;
-    pacer.signal_upto((r + 1) * s.steps);
-  }
-  pacer.report(s.dbg, t_start);
+template <int L, int NV, int HV, bool OFF32 = true>
+__global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f32(   // (second bound: waves per SIMD)
+    WalkView s, const float* __restrict__ wgt, const float* __restrict__ X, float* __restrict__ out, int d4) {
+  spmm_walk_body<L, NV, HV, float, OFF32>(s, wgt, X, out, d4);
+}
+// fp64 (the reference dispatches both types through the same kernels, graphop_kernel.cu:291): one head, rows of 16 * L bytes
+template <int L, int NV, bool OFF32 = true>
+__global__ __launch_bounds__(kWalkThreads, 3) void k_spmm_walk_f64(
+    WalkView s, const double* __restrict__ wgt, const double* __restrict__ X, double* __restrict__ out) {
+  spmm_walk_body<L, NV, 1, double, OFF32>(s, wgt, X, out, L);
 }
 
 }  // namespace graphop

@@ -135,20 +135,6 @@ __global__ void k_plan_long_segs(const i64* __restrict__ seg_chunk, const i64* _
   }
 }
 
-__global__ void k_inv_scatter(const int32_t* __restrict__ eid32, i64 n, int32_t* __restrict__ inv) {
-  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (; k < n; k += stride) inv[eid32[k]] = (int32_t)k;
-}
-__global__ void k_inv_check(const int32_t* __restrict__ eid32, const int32_t* __restrict__ inv, i64 n,
-                            int* __restrict__ bad) {
-  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  int b = 0;
-  for (; k < n; k += stride) b |= inv[eid32[k]] != (int32_t)k;
-  if (b) atomicOr(bad, 1);
-}
-
 __global__ void k_narrow(const i64* __restrict__ src, int32_t* __restrict__ dst, i64 n) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -787,9 +773,8 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
   if (go_malloc((void**)&s.vr_row, sizeof(int) * (size_t)V, st) != hipSuccess ||
       go_malloc((void**)&s.wp_lo, wp_bytes, st) != hipSuccess ||
       go_malloc((void**)&s.wp_hi, wp_bytes, st) != hipSuccess ||
-      go_malloc((void**)&s.sync, sizeof(int) * kSweepSyncInts, st) != hipSuccess ||
       go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
-    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync);
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
     go_free(s.queues);
     set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
     return GRAPHOP_ERR_HIP;
@@ -888,6 +873,7 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
     const int rc_cap = check_not_capturing(st, "building the walk layout of a plan");
     if (rc_cap != GRAPHOP_OK) return rc_cap;
   }
+  (void)device_error_word(true);   // the walk kernels report hand-over timeouts there; created here, outside any capture
   const i64 S = p->info.n_segments, E = p->info.n_edges;
   GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E > 0 && E < 0x7fffffffLL && S > 0 &&
                W >= 1 && groups >= 1 && GW >= 1 && GW <= 4 && groups % GW == 0 && K >= 1 && K <= kWalkK,
@@ -1014,7 +1000,7 @@ void plan_free_sweeps(graphop_plan* p) {
   auto* vec = (std::vector<Sweep>*)p->sweeps;
   if (vec) {
     for (auto& s : *vec) {
-      go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync);
+      go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
       go_free(s.queues);
       for (int i = 0; i < s.n_dealt; ++i) { go_free(s.dealt[i].rec); go_free(s.dealt[i].ids); go_free(s.dealt[i].eids); }
     }
@@ -1092,48 +1078,12 @@ int plan_import_sweep(graphop_plan* p, int W, i64 win_cols, int T, int V, const 
     go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
     return rc;
   }
-  if (go_malloc((void**)&s.sync, sizeof(int) * kSweepSyncInts, st) != hipSuccess ||
-      go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
-    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.sync); go_free(s.queues);
+  if (go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.queues);
     set_error("plan_import_sweep: out of device memory");
     return GRAPHOP_ERR_HIP;
   }
   vec->push_back(s);
-  return GRAPHOP_OK;
-}
-
-// Inverse of eid (slot of every edge id) + a float scratch of n_edges values, built on first use.
-// Returns GRAPHOP_OK with p->inv_state == 1 when available, -1 when eid is not a permutation.
-int plan_get_inverse(graphop_plan* p, hipStream_t st) {
-  auto* mu = (std::mutex*)p->sweep_mu;
-  std::lock_guard<std::mutex> lk(*mu);
-  if (p->inv_state != 0) return GRAPHOP_OK;
-  {
-    const int rc_cap = check_not_capturing(st, "building the inverse edge permutation of a plan");
-    if (rc_cap != GRAPHOP_OK) return rc_cap;
-  }
-  const i64 E = p->info.n_edges;
-  p->inv_state = -1;
-  if (!p->eid32 || E <= 0 || E >= 0x7fffffffLL) return GRAPHOP_OK;
-  DevBuf bad;
-  GO_HIP(go_malloc(&bad.p, sizeof(int), st));
-  GO_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
-  GO_HIP(go_malloc((void**)&p->inv32, sizeof(int32_t) * (size_t)E, st));
-  GO_HIP(hipMemsetAsync(p->inv32, 0xff, sizeof(int32_t) * (size_t)E, st));
-  hipLaunchKernelGGL(k_inv_scatter, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st,
-                     (const int32_t*)p->eid32, E, p->inv32);
-  hipLaunchKernelGGL(k_inv_check, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st,
-                     (const int32_t*)p->eid32, (const int32_t*)p->inv32, E, (int*)bad.p);
-  GO_LAUNCH_CHECK();
-  int h_bad = 1;
-  GO_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  GO_HIP(hipStreamSynchronize(st));
-  if (h_bad) { go_free(p->inv32); p->inv32 = nullptr; return GRAPHOP_OK; }
-  if (go_malloc((void**)&p->scalar_scratch, sizeof(float) * (size_t)E, st) != hipSuccess) {
-    go_free(p->inv32); p->inv32 = nullptr; p->scalar_scratch = nullptr;
-    return GRAPHOP_OK;
-  }
-  p->inv_state = 1;
   return GRAPHOP_OK;
 }
 

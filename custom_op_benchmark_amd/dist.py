@@ -134,16 +134,24 @@ def run_local_shards(world, fn, timeout=300.0):
 
 class ShardedAttention:
     def __init__(self, rank, world, bounds, src_global, dst_global, device, chunk_size=32, ops=None,
-                 group=None, timing_only=False):
+                 group=None, timing_only=False, force_collectives=False, halo_mask=None):
         """src_global/dst_global: the edges whose source lies in this rank's range (any order).
         group: a torch.distributed process group (None = default), or a LocalGroup handle (all shards
         in this process, exchanges are device copies: exact results on one GPU).
         timing_only=True builds ONE shard with no peers at all: exchanges become local copies of the
         right sizes, so the shard's kernels see the right shapes and the step can be timed when the
         other shards do not fit next to it (bench.py --emulate-world on papers100M-size shards).
-        Values involving halo rows are then meaningless and must not be checked."""
+        Values involving halo rows are then meaningless and must not be checked.
+        force_collectives=True (or GRAPHOP_DIST_FORCE_COLLECTIVES=1) keeps the real collective calls at
+        world == 1 too -- all_to_all_single on a one-rank process group, async handles, split-size views --
+        so that the RCCL code path runs on a one-GPU box (tests/test_dist_gpu.py, bench.py --rccl-self);
+        halo_mask (bool per edge) then marks edges whose destination is to be FETCHED THROUGH THE EXCHANGE
+        although this rank owns it (the rank is its own peer): real bytes move through every exchange and
+        the re-assembled result is still exact."""
         self.rank, self.world, self.bounds, self.group = rank, world, list(bounds), group
         self.emulate = timing_only
+        import os
+        self.force = bool(force_collectives) or os.environ.get("GRAPHOP_DIST_FORCE_COLLECTIVES", "0") == "1"
         self.local = group if isinstance(group, _LocalHandle) else None
         self._buffers = {}
         self.timers = None       # set to {} to collect per-exchange wall times (bench.py)
@@ -159,6 +167,8 @@ class ShardedAttention:
         assert src_global.numel() == 0 or (int(src_global.min()) >= lo and int(src_global.max()) < hi)
 
         own = (dst_global >= lo) & (dst_global < hi)
+        if halo_mask is not None:
+            own &= ~halo_mask.to(self.device)
         remote = dst_global[~own]
         halo_ids = torch.unique(remote)                       # sorted global ids of halo nodes
         self.n_halo = int(halo_ids.numel())
@@ -188,7 +198,7 @@ class ShardedAttention:
     def _exchange_counts(self, counts):
         t_in = torch.tensor(counts, dtype=torch.int64, device=self.device)
         t_out = torch.empty_like(t_in)
-        if self.world == 1 or self.emulate:
+        if (self.world == 1 and not self.force) or self.emulate:
             return counts
         if self.local is not None:
             return self.local.group.exchange_counts(self.rank, counts)
@@ -217,7 +227,7 @@ class ShardedAttention:
         """Variable-size all-to-all (splits count rows).  Returns a handle whose wait() orders the
         current stream (RCCL) / the caller (gloo) after the exchange; already complete unless
         async_op was requested on a real process group."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             out.copy_(inp)
             return _DONE
         if self.emulate:
@@ -333,7 +343,7 @@ class ShardedAttention:
         da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
         # backward exchange: partial rows computed for halo columns go home and are added there;
         # the dV rows travel while the softmax and SDDMM backward run
-        exchange = self.n_halo or self.world > 1
+        exchange = self.n_halo or self.world > 1 or self.force
         dV = dV_ext[:n_own]                                     # views: updated in place
         if exchange:
             wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True, role="dV")
@@ -437,24 +447,28 @@ class ShardedAttention:
 
     # ---- builders --------------------------------------------------------------------------------
     @classmethod
-    def from_global_coo(cls, src, dst, n_nodes, rank, world, device, chunk_size=32, ops=None, group=None):
+    def from_global_coo(cls, src, dst, n_nodes, rank, world, device, chunk_size=32, ops=None, group=None,
+                        force_collectives=False, halo_mask=None):
         """Every rank holds the full edge list (small graphs / tests); ranges balanced by edges."""
         deg = torch.bincount(src.to(torch.int64), minlength=n_nodes)
         bounds = balanced_ranges(deg, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         m = (src >= lo) & (src < hi)
-        return cls(rank, world, bounds, src[m], dst[m], device, chunk_size, ops, group)
+        return cls(rank, world, bounds, src[m], dst[m], device, chunk_size, ops, group,
+                   force_collectives=force_collectives, halo_mask=None if halo_mask is None else halo_mask.to(m.device)[m])
 
     @classmethod
     def synthetic(cls, n_per_rank, e_per_rank, world, rank, device, alpha=0.5, seed=0, chunk_size=32,
-                  ops=None, group=None, timing_only=False, cut=1.0):
+                  ops=None, group=None, timing_only=False, cut=1.0, force_collectives=False, self_halo=False):
         """Weak-scaling bench graph: `world` equal node ranges of a Chung-Lu graph with
         world*n_per_rank nodes; each rank draws the e_per_rank edges of its own rows on its own
         device.  Sources come from its range; a destination comes from the GLOBAL weight vector with
         probability `cut` and from the rank's own range otherwise.  cut = 1 is a graph without any
         locality (every rank's halo is nearly every remote node: the worst case for a node-range
         partition); cut ~ 0.1 is what a locality-aware partition of a citation graph leaves
-        (stated in bench.py's config line)."""
+        (stated in bench.py's config line).  self_halo=True (with force_collectives, world == 1 rehearsals of the
+        RCCL path): the destinations drawn from the global distribution are fetched through the exchange even
+        where the rank owns them."""
         n_total = n_per_rank * world
         w = graphs.powerlaw_weights(n_total, alpha, seed, device)
         bounds = [p * n_per_rank for p in range(world + 1)]
@@ -463,7 +477,7 @@ class ShardedAttention:
         w_own = w[lo:hi] / w[lo:hi].sum()
         cdf_own = torch.cumsum(w_own, 0); cdf_own[-1] = 1.0
         gen = torch.Generator(device=device).manual_seed(seed + 1000 * (rank + 1))
-        srcs, dsts = [], []
+        srcs, dsts, glob = [], [], []
         batch = 1 << 26
         for s0 in range(0, e_per_rank, batch):
             m = min(batch, e_per_rank - s0)
@@ -476,9 +490,14 @@ class ShardedAttention:
                 d_own = lo + torch.searchsorted(cdf_own, u).clamp_(max=n_per_rank - 1)
                 keep = torch.rand(m, generator=gen, device=device) < cut
                 d_glob = torch.where(keep, d_glob, d_own)
+                if self_halo:
+                    glob.append(keep)
+            elif self_halo:
+                glob.append(torch.ones(m, dtype=torch.bool, device=device))
             dsts.append(d_glob)
         return cls(rank, world, bounds, torch.cat(srcs), torch.cat(dsts), device, chunk_size, ops, group,
-                   timing_only)
+                   timing_only, force_collectives=force_collectives,
+                   halo_mask=torch.cat(glob) if self_halo else None)
 
     @classmethod
     def synthetic_rmat(cls, scale, e_per_rank, world, rank, device, seed=0, chunk_size=32, ops=None,

@@ -49,7 +49,7 @@ extern "C" {
 #define GRAPHOP_API
 #endif
 
-#define GRAPHOP_ABI_VERSION 5
+#define GRAPHOP_ABI_VERSION 6
 
 #define GRAPHOP_F32 0
 #define GRAPHOP_F64 1
@@ -82,19 +82,28 @@ typedef struct graphop_plan_info {
 
 GRAPHOP_API int graphop_abi_version(void);
 GRAPHOP_API const char* graphop_last_error(void);
+/* Device-side failures.  The walk kernels' hand-overs between worker and feeder waves are bounded spins (a launch
+ * must not be able to hang the device); a spin whose bound expires does NOT fall through: the wave stores a code in
+ * a host-visible word, its workgroup aborts, and the outputs of that launch are invalid.  Launches are asynchronous,
+ * so -- like a HIP error of a kernel -- the failure is reported by the NEXT entry point that looks: every compute
+ * entry point checks the word first and fails with GRAPHOP_ERR_HIP and a message, and this call checks it on demand
+ * (synchronise the stream first to learn about the launches before it).  Reading clears the word.  ABI 6. */
+GRAPHOP_API int graphop_check_device_errors(void);
 
 /* ---- tuning knobs (also read once from the environment as GRAPHOP_<KEY>) ----------------------
  * keys: sddmm_cpg, spmm_cpg (chunks per lane group of the chunk drivers), force_generic,
- * sweep (0/1), sweep_mode (1 = XCDs own column windows and waves pull (window, row tile) tasks;
- * 0 = workgroups own rows and walk the windows in step), window_kb, mall_window_kb, max_windows,
- * sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_drift, sweep_min_granule, sweep_prefetch,
- * transpose_scalars, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
+ * sweep (0/1: window-owner drivers -- XCDs own column windows and waves pull (window, row tile) tasks),
+ * window_kb, mall_window_kb, max_windows, sweep_min_kb, sweep_bpc, sweep_k, vrow_t, sweep_min_granule,
+ * sweep_w, spmm_window_scale, staged_ids, dense_blocks (0/1: fp32-MFMA block-dense drivers when the plan found a
  * cover), dense_min_fill, dense_detect_min_fill (percent of a 32x32 tile), attn_fused (0/1),
  * attn_window_scale, attn_k, attn_bpc (fused attention kernels), touch_sddmm (per-task id-line
- * touches of the SDDMM strips), walk (bit 0 SDDMM-type, bit 1 row-major SpMM-type, bit 2 column-major
- * SpMM-type passes on the walk drivers: lane groups own rows for a whole round and walk all column
- * windows, nothing is flushed per window), walk_window_kb, walk_drift, walk_min_bin.  Not
- * thread-safe against concurrent op calls; results never depend on them. */
+ * touches of the SDDMM strips), walk (bit 1 row-major SpMM-type, bit 2 column-major SpMM-type passes on
+ * the walk drivers: lane groups own rows for a whole round and walk all column windows, nothing is
+ * flushed per window), walk_window_kb, walk_window_kb_col, walk_drift, walk_steps, walk_min_bin,
+ * walk_blocks, walk_debug, walk_fault (tests: hand-over fault injection).  Not thread-safe against
+ * concurrent op calls; results never depend on them.  (Removed in ABI 6: sweep_mode, sweep_drift,
+ * sweep_prefetch, transpose_scalars -- the paced vrow-owner sweep and the scalar transpose pre-pass,
+ * both measured slower than what replaced them.) */
 GRAPHOP_API int graphop_tune(const char* key, int value);
 /* Every knob back to its default (the value at library load: built-in, or GRAPHOP_<KEY> from the
  * environment).  Tests that turn knobs restore them with this, never with literals. */
@@ -108,7 +117,8 @@ GRAPHOP_API int64_t graphop_memory_bytes(void);
 
 /* ---- device memory of plans ------------------------------------------------------------------
  * Plans own device arrays (per orientation: 8 B per chunk, 4-8 B per edge of 32-bit mirrors, and
- * 8 B x windows x rows per window geometry in use; Reddit-shape: ~1.4 GB for both orientations).
+ * 8 B x windows x rows per window geometry in use, 4-8 B per edge per dealt / walk layout;
+ * Reddit-shape: ~5.2 GB for both orientations once every pass of the step has run).
  * By default they come from hipMalloc / hipFree (each a device-wide synchronisation).  A binding
  * may route them through its framework's allocator: alloc_fn(bytes, device, stream) returns a
  * device pointer usable on `stream` (NULL = out of memory), free_fn(ptr) releases it with

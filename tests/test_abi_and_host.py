@@ -129,7 +129,7 @@ def test_hot_kernels_do_not_spill():
     from kernel_resources import kernel_resources
     res = kernel_resources()
     hot = {n: r for n, r in res.items()
-           if re.search(r"k_(sddmm|spmm)_(wown|sweep|block|wown_staged|walk)_f32|k_softmax_(fwd|bwd)_(seg|vec4)|k_attn_bwd_wown_f32|k_nme_", n)}
+           if re.search(r"k_(sddmm|spmm)_(wown|block|wown_staged|walk)_f(32|64)|k_softmax_(fwd|bwd)_(seg|vec4)|k_attn_bwd_wown_f32|k_nme_", n)}
     assert len(hot) > 100, len(hot)
     bad = {n: r for n, r in hot.items() if r["spill_vgpr"] or r["scratch"]}
     assert not bad, "\n".join("%s: %r" % kv for kv in sorted(bad.items()))

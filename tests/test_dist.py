@@ -122,3 +122,35 @@ def test_rmat_shard_edges_stay_in_range():
     # Graph500 marginals: P(src top bit = 0) = a + b = 0.76, P(dst top bit = 0) = a + c = 0.76
     assert abs(float((s2 < 512).float().mean()) - 0.76) < 0.02
     assert abs(float((d2 < 512).float().mean()) - 0.76) < 0.02
+
+
+def _self_halo_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
+        inp = rand_inputs(g, 2, 8, seed=22, normal=True)
+        mask = torch.rand(g.src.numel(), generator=torch.Generator().manual_seed(5)) < 0.5
+        calls = []
+        real = dist.all_to_all_single
+        dist.all_to_all_single = lambda *a, **k: (calls.append(bool(k.get("async_op"))), real(*a, **k))[1]
+        sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle,
+                                              force_collectives=True, halo_mask=mask)
+        assert sh.n_halo > 0 and sh.recv_counts == [sh.n_halo] and len(calls) == 2
+        r = sh.step(inp["Q"], inp["K"], inp["V"], inp["dO"])
+        assert len(calls) == 6 and all(calls[2:])           # K, V, dV, dK went through the process group, async
+        want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+        for k in ("o", "dQ", "dK", "dV"):
+            torch.testing.assert_close(r[k], want[k], rtol=1e-4, atol=1e-5)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one(tmp_path):
+    """force_collectives: a one-rank process group still goes through all_to_all_single (no world == 1 short-cut),
+    and a self-halo (halo_mask) makes the exchanges move real rows: the CPU twin of
+    tests/test_dist_gpu.py::test_rccl_path_at_world_size_one."""
+    mp.spawn(_self_halo_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))

@@ -119,3 +119,62 @@ def test_two_shards_at_scale_vs_cpu_path(dev):
     for name, want in (("o", o0), ("dQ", dQ0), ("dK", dK0), ("dV", dV0)):
         got = torch.cat([z[name] for z in parts]).cpu()
         torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5, msg=lambda m: name + ": " + m)
+
+
+_RCCL_CHILD = r'''
+import os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, os.path.join(sys.argv[2], "tests"))
+import torch, torch.distributed as dist
+import oracle
+from custom_op_benchmark_amd.dist import ShardedAttention
+from util import oracle_step, rand_inputs, random_graph
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
+assert dist.get_backend() == "nccl"
+calls = {"n": 0, "async": 0}
+real = dist.all_to_all_single
+def counted(*a, **k):
+    calls["n"] += 1; calls["async"] += 1 if k.get("async_op") else 0
+    return real(*a, **k)
+dist.all_to_all_single = counted
+for h, d in ((1, 64), (2, 16)):
+    g = random_graph(600, 600, 20000, seed=31 + h, chunk_size=8, zero_rows=0.1, hub=700)
+    inp = rand_inputs(g, h, d, seed=32, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    mask = torch.rand(g.src.numel(), generator=torch.Generator().manual_seed(5)) < 0.5   # half of the edges: fetched through RCCL
+    n0 = calls["n"]
+    sh = ShardedAttention.from_global_coo(g.src.to(dev), g.dst.to(dev), g.n_src, 0, 1, dev, chunk_size=8,
+                                          force_collectives=True, halo_mask=mask)
+    assert sh.n_halo > 0 and sh.recv_counts == [sh.n_halo] and sh.send_counts == [sh.n_halo]
+    assert calls["n"] - n0 == 2                      # setup: counts, then the id lists -- through the process group
+    n0, a0 = calls["n"], calls["async"]
+    r = sh.step(*(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
+    torch.cuda.synchronize()
+    assert calls["n"] - n0 == 4 and calls["async"] - a0 == 4, calls     # K, V, dV, dK: asynchronous RCCL all-to-alls
+    ext_ids = torch.cat([torch.arange(0, g.n_src, device=dev), sh.halo_ids])
+    key = (sh.graph.src * g.n_dst + ext_ids[sh.graph.dst]).cpu()
+    order = torch.argsort(key, stable=True)
+    for k in ("o", "dQ", "dK", "dV"):
+        torch.testing.assert_close(r[k].detach().cpu(), want[k], rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
+    for k in ("s", "a"):
+        torch.testing.assert_close(r[k].detach().cpu()[order], want[k], rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+'''
+
+
+def test_rccl_path_at_world_size_one(dev):
+    """The REAL collective path on a one-GPU box: a one-rank `nccl` (= RCCL) process group in a spawned child,
+    ShardedAttention with force_collectives (no world == 1 short-cut) and a self-halo -- half of the edges fetch
+    their K / V rows through all_to_all_single(async_op=True) + work.wait() with split-size views, and send their
+    dK / dV rows home the same way -- result == the single-process oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(29500 + os.getpid() % 2000)
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD, port, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

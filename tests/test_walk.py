@@ -1,5 +1,5 @@
-"""Walk drivers (csrc/kernels_walk.h): lane groups own a bin of rows for a whole round, keep the rows
-(partial sums / A rows) in LDS and walk all column windows; the plan cuts the CSR into equal bins
+"""Walk drivers (csrc/kernels_walk.h): lane groups own a bin of rows for a whole round, keep the rows'
+partial sums in LDS and walk all column windows; the plan cuts the CSR into equal bins
 (csrc/plan.hip: plan_get_walk).  Forced on small graphs through the tuning knobs, checked against
 the oracle, against the window-owner drivers and against the chunk drivers."""
 import pytest
@@ -12,14 +12,14 @@ from test_hip_parity import hip_step, close
 
 pytestmark = pytest.mark.gpu
 
-WALK_KERNELS = {"k_sddmm_walk_f32", "k_spmm_walk_f32"}
+WALK_KERNELS = {"k_spmm_walk_f32"}
 
 
 @pytest.fixture
 def force_walk():
     _lib.tune_reset()
     _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 8); _lib.tune("walk_window_kb_col", 8); _lib.tune("walk_min_bin", 0)
-    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512); _lib.tune("walk", 7)
+    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512); _lib.tune("walk", 6)
     _lib.clear_plan_cache()
     yield
     _lib.tune_reset()
@@ -123,7 +123,7 @@ def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk, h, d
     held = _lib.plan_memory_bytes()
     want = hip_step(g, Q, K, V, dO)
     assert _lib.plan_memory_bytes() == held            # the eager step built nothing after prepare
-    assert (WALK_KERNELS if h == 1 else {"k_spmm_walk_f32"}) <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
+    assert WALK_KERNELS <= kernels_of(lambda: hip_step(g, Q, K, V, dO))
     a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
     s = ops.maskedmm_csr_forward(*a4, Q, K)
     a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
@@ -142,3 +142,105 @@ def test_prepare_builds_walk_layouts_and_the_step_captures(dev, force_walk, h, d
     dQ2, dK2 = ops.maskedmm_csr_backward(*g.csr_args(), Q, K, a)
     torch.testing.assert_close(dQ, dQ2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dK, dK2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("fault,what", [(1, "ring chunk"), (2, "previous step")])
+def test_hand_over_timeout_is_an_error_not_a_wrong_result(dev, force_walk, fault, what):
+    """The worker <-> feeder and quad hand-overs of the walk kernel are bounded spins (a launch must not hang the
+    device).  When a bound expires the wave must NOT carry on with whatever the ring holds: the workgroup aborts,
+    a code lands in the host-visible error word and the library raises (include/graphop_hip.h:
+    graphop_check_device_errors).  Forced with the fault-injection knob: 1 = a feeder never publishes one chunk,
+    2 = a quad never reports its first step finished.  Run once; afterwards the library works again."""
+    from custom_op_benchmark_amd import graphop as ops
+    _lib.tune("walk_blocks", 8)
+    g = random_graph(1500, 1500, 30000, seed=21, chunk_size=32, hub=900).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(6)
+    V = torch.randn(1500, 64, device=dev, generator=gen)
+    a = torch.rand(g.eid_r.numel(), device=dev, generator=gen)
+    a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+    good = ops.vector_spmm_forward(*a4, a, V)
+    _lib.check_errors()                               # nothing reported by a healthy launch
+    _lib.tune("walk_fault", fault)
+    ops.vector_spmm_forward(*a4, a, V)                # asynchronous: the launch itself returns
+    with pytest.raises(RuntimeError, match=what):
+        _lib.check_errors()                           # synchronises, then looks at the error word
+    _lib.tune("walk_fault", 0)
+    ops.vector_spmm_forward(*a4, a, V)                # a failed launch is reported by the next entry point too ...
+    _lib.tune("walk_fault", fault)
+    ops.vector_spmm_forward(*a4, a, V)
+    torch.cuda.synchronize()
+    _lib.tune("walk_fault", 0)
+    with pytest.raises(RuntimeError, match="walk kernel"):
+        ops.vector_spmm_forward(*a4, a, V)            # ... here: the entry point checks the word before launching
+    again = ops.vector_spmm_forward(*a4, a, V)        # the word was cleared by the report
+    _lib.check_errors()
+    torch.testing.assert_close(again, good, rtol=1e-5, atol=1e-6)
+
+
+def kernels_by_tag(step):
+    _lib.profile_enable(True)
+    step()
+    torch.cuda.synchronize()
+    k = {tag: r.get("kernel") for tag, r in _lib.profile_read().items()}
+    _lib.profile_enable(False)
+    return k
+
+
+@pytest.mark.parametrize("blocks", [8, 0])
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_fp64_on_the_walk_and_window_drivers_vs_oracle(dev, force_walk, d, blocks):
+    """fp64 takes the same plan-driven kernels as fp32 (the reference dispatches both types through the same
+    kernels, graphop_kernel.cu:291): rows of 256 B / 512 B / 1 KB = the lane-group shapes of fp32 d = 64 / 128 / 256.
+    Forced small geometry: SDDMM-type passes on the staged window-owner strip, SpMM-type passes (row- and
+    column-major) on the walk kernel, 8-byte weights through the feeder rings, dense fp64 atomics for the rows
+    a bin shares; against the oracle at the fp64 tolerance."""
+    from test_hip_parity import TOL
+    _lib.tune("walk_blocks", blocks); _lib.tune("window_kb", 8); _lib.tune("vrow_t", 64)
+    n = 400 if d >= 128 else 1500
+    g = random_graph(n, n + 41, 10 * n, seed=5 + d + blocks, chunk_size=32, zero_rows=0.15, hub=900)
+    inp = rand_inputs(g, 1, d, seed=8, dtype=torch.float64, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+    got = hip_step(gd, *args)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        close(got[k], want[k], torch.float64)
+    kern = kernels_by_tag(lambda: hip_step(gd, *args))
+    assert kern["sddmm_fwd"] == kern["spmm_bwd_dedata"] == "k_sddmm_wown_staged_f64", kern
+    assert all(kern[t] == "k_spmm_walk_f64" for t in ("spmm_fwd", "spmm_bwd_dx", "sddmm_bwd_dA", "sddmm_bwd_dB")), kern
+    # the generic kernels (another family) agree
+    _lib.tune("force_generic", 1)
+    ref = hip_step(gd, *args)
+    for k in ("s", "a", "o", "dQ", "dK", "dV"):
+        torch.testing.assert_close(got[k], ref[k], rtol=1e-10, atol=1e-12)
+
+
+def test_tables_of_4gib_and_more_take_64bit_row_offsets(dev, force_walk):
+    """Walk and staged window-owner kernels on a gathered table of >= 4 GiB (64-bit row offsets instead of the
+    32-bit vector offset): a 4.3 GB table of 256-B rows with a few thousand edges whose neighbours lie at both
+    ends of it, against the chunk drivers (which always used 64-bit indexing)."""
+    n_cols = (1 << 24) + 1024                                  # x 256 B = 4.0 GiB + 256 KB
+    n_rows = 1500
+    gen = torch.Generator().manual_seed(3)
+    src = torch.randint(0, n_rows, (40000,), generator=gen)
+    dst = torch.cat([torch.randint(0, 3000, (20000,), generator=gen), n_cols - 1 - torch.randint(0, 3000, (20000,), generator=gen)])
+    g = graphs.graph_from_coo(src, dst, n_rows, n_cols, chunk_size=32).to(dev)
+    _lib.tune("walk_blocks", 8); _lib.tune("window_kb", 1 << 19); _lib.tune("walk_window_kb", 1 << 19)
+    _lib.tune("walk_window_kb_col", 1 << 19); _lib.tune("vrow_t", 64)
+    K = torch.zeros(n_cols, 64, device=dev)
+    gk = torch.Generator(device=dev).manual_seed(4)
+    K[:3000] = torch.randn(3000, 64, device=dev, generator=gk); K[-3000:] = torch.randn(3000, 64, device=dev, generator=gk)
+    Q = torch.randn(n_rows, 64, device=dev, generator=gk)
+    w = torch.rand(g.eid_r.numel(), device=dev, generator=gk)
+    from custom_op_benchmark_amd import graphop as ops
+    a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+    kern = kernels_by_tag(lambda: (ops.maskedmm_csr_forward(*a4, Q, K), ops.vector_spmm_forward(*a4, w, K)))
+    assert kern["sddmm_fwd"] == "k_sddmm_wown_staged_f32" and kern["spmm_fwd"] == "k_spmm_walk_f32", kern
+    s1 = ops.maskedmm_csr_forward(*a4, Q, K)
+    o1 = ops.vector_spmm_forward(*a4, w, K)[:n_rows]
+    _lib.tune("sweep", 0); _lib.tune("walk", 0)
+    s0 = ops.maskedmm_csr_forward(*a4, Q, K)
+    o0 = ops.vector_spmm_forward(*a4, w, K)[:n_rows]
+    torch.testing.assert_close(s1, s0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-5)
+    assert float(s0.abs().max()) > 0 and float(o0.abs().max()) > 0

@@ -2,7 +2,7 @@
 """Knob sweep for the gather passes: build one graph, then time the attention step per pass
 (library hipEvent profiler) under a list of tuning-knob settings.
 
-  python tools/tune_sweep.py [--graph reddit] [--d 64] [--heads 1] "sweep_mode=1,vrow_t=1024" "sweep_mode=0" ...
+  python tools/tune_sweep.py [--graph reddit] [--d 64] [--heads 1] "vrow_t=1024" "walk=0" ...
 
 Each positional argument is one setting (comma-separated key=value pairs on top of the defaults).
 Prints one line per setting: step ms and the per-pass ms.  Speed only: results never depend on the
@@ -12,9 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from custom_op_benchmark_amd import _lib, graphs, functions
 
-DEFAULTS = dict(sweep=1, sweep_mode=1, window_kb=4096, mall_window_kb=32768, max_windows=128,
-                sweep_min_kb=4608, sweep_bpc=3, sweep_k=0, vrow_t=0, sweep_drift=2, sweep_min_granule=4,
-                sweep_prefetch=0, transpose_scalars=0, sweep_w=0, spmm_window_scale=2,
+DEFAULTS = dict(sweep=1, window_kb=4096, mall_window_kb=32768, max_windows=128,
+                sweep_min_kb=4608, sweep_bpc=3, sweep_k=0, vrow_t=0, sweep_min_granule=4,
+                sweep_w=0, spmm_window_scale=2,
                 attn_fused=1, attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1, staged_ids=7,
                 walk=6, walk_window_kb=4096, walk_window_kb_col=2048, walk_drift=3, walk_min_bin=1024, walk_blocks=0, walk_steps=2)
 
