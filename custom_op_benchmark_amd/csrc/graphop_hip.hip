@@ -184,7 +184,7 @@ int check_async_error() {
   if (code == 0) return GRAPHOP_OK;
   const char* what = code == kWalkErrQuad ? "a (step, quad) unit waited for its quad's previous step"
                    : code == kWalkErrRing ? "a worker wave waited for a ring chunk of its feeder wave"
-                   : code == kWalkErrFeeder ? "a feeder wave waited for ring space" : "unknown code";
+                   : "unknown code";
   set_error("a walk kernel (k_spmm_walk_f32) of an earlier launch aborted: %s until its spin bound expired (device "
             "error code %d); the outputs of that launch are invalid", what, code);
   return GRAPHOP_ERR_HIP;

@@ -53,13 +53,25 @@ struct WalkView {
 // The XCD pacer is different: results never depend on it, it gives up silently.
 constexpr int kWalkErrQuad = 1;     // a (step, quad) unit waited for the quad's previous step
 constexpr int kWalkErrRing = 2;     // a worker waited for a ring chunk of its feeder
-constexpr int kWalkErrFeeder = 3;   // a feeder waited for ring space
 constexpr int kWalkSpinQuad = 1 << 24;    // x s_sleep(1): ~1 s
 constexpr int kWalkSpinRing = 1 << 22;    // x s_sleep(1): ~0.25 s
-constexpr int kWalkSpinFeeder = 1 << 23;  // x s_sleep(4): ~2 s
-__device__ __forceinline__ void walk_fail(int* err, int* wg_abort, int code) {
-  __hip_atomic_store(wg_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// the workgroup's abort flag as a WAVE-UNIFORM value: an exit that depends on a plain LDS read is divergent control flow
+// to the compiler -- the feeder's bookkeeping (scalar registers, scalar branches) turned into exec-mask code and
+// lane spills with it: 1.69 -> 2.33 ms per pass
+__device__ __forceinline__ int walk_aborted(const int* wg_abort) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(wg_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+// walk_fail raises the workgroup's abort flag (LDS: the code); the host-visible word is written ONCE, by the worker
+// waves on their way out (walk_report).  No global store may sit inside the feeder's or the workers' loops: on gfx950
+// loads and stores share the vmcnt counter, and with a store in the loop body -- however cold its path -- the
+// compiler drains the loads the feeder keeps in flight across its turns (measured: +0.65 ms per pass).
+__device__ __forceinline__ void walk_fail(int* wg_abort, int code) {
+  __hip_atomic_store(wg_abort, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void walk_report(int* err, const int* wg_abort) {
+  const int code = walk_aborted(wg_abort);
+  if (code != 0 && err != nullptr && (threadIdx.x & (kWave - 1)) == 0)
+    __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int kWalkIdMask = (1 << kWalkKShift) - 1;
@@ -260,7 +272,7 @@ __device__ __forceinline__ void spmm_walk_body(
     // advance independently of each other.
     const int h = (threadIdx.x - kWalkWorkers) % kWave;
     constexpr int NG = GPB / kFeeders > 0 ? GPB / kFeeders : 1;   // lane groups of this feeder
-    const int g0 = ((threadIdx.x - kWalkWorkers) / kWave) * NG;
+    const int g0 = __builtin_amdgcn_readfirstlane(((threadIdx.x - kWalkWorkers) / kWave) * NG);   // (wave-uniform, and known to be)
     if (g0 >= GPB) return;
     int chunk_base[NG];                               // chunks of earlier rounds (wave-uniform)
 #pragma unroll
@@ -301,7 +313,7 @@ __device__ __forceinline__ void spmm_walk_body(
           if (j < total[g]) wi = __builtin_nontemporal_load(s.widx + pos0[g] + jc);
         }
       };
-      int left = 0, idle = 0;
+      int left = 0;
       {
         int p_l = 0, t_l = 0;                         // lane g < NG: run start / length of lane group g0 + g
         if (h < NG) {
@@ -357,13 +369,14 @@ __device__ __forceinline__ void spmm_walk_body(
         }
         if (adv == 0) {
           const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
-          __builtin_amdgcn_s_sleep(4);
+          __builtin_amdgcn_s_sleep(4);                    // (1 / 16 / 48 measured the same: 1.68 / 2.21 ms per pass)
           if (s.dbg) t_space += __builtin_amdgcn_s_memtime() - t0;
-          if (lds_ld(&wg_abort)) return;
-          if (++idle > kWalkSpinFeeder) { walk_fail(s.err, &wg_abort, kWalkErrFeeder); return; }
+          // (no bound of its own: ring space comes from the worker waves, whose waits are all bounded and end in the
+          // abort flag; a spin counter here -- one more live scalar and one more loop exit in the feeder's turn --
+          // measured +0.65 ms per pass, profiles/r4_experiments.txt)
+          if (walk_aborted(&wg_abort)) return;
           continue;
         }
-        idle = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           if (!((adv >> g) & 1)) continue;
@@ -407,16 +420,15 @@ __device__ __forceinline__ void spmm_walk_body(
       t = __hip_atomic_fetch_add(&tk_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     t = __builtin_amdgcn_readfirstlane(t);
     const int gstep = t / NQ, q = t % NQ;             // step-major: the quads of a step are taken before the next step's
-    if (gstep >= n_steps) break;
+    if (gstep >= n_steps || walk_aborted(&wg_abort)) break;
     const int r = gstep / s.steps, sidx = gstep - r * s.steps;
     {
-      int it = 0;                                     // (wave-uniform loop: every lane polls the same words)
-      bool dead = false;
+      int it = 0, dead = 0;                           // (every lane polls the same words: the values are made wave-uniform)
       const long long t0 = s.dbg ? __builtin_amdgcn_s_memtime() : 0;
-      while (lds_ld(quad_done + q) < gstep) {         // the quad's previous step is still being worked on
+      while (__builtin_amdgcn_readfirstlane(lds_ld(quad_done + q)) < gstep) {   // the quad's previous step is still being worked on
         __builtin_amdgcn_s_sleep(1);
-        if (lds_ld(&wg_abort)) { dead = true; break; }
-        if (++it > kWalkSpinQuad) { walk_fail(s.err, &wg_abort, kWalkErrQuad); dead = true; break; }
+        if (walk_aborted(&wg_abort)) { dead = 1; break; }
+        if (++it > kWalkSpinQuad) { walk_fail(&wg_abort, kWalkErrQuad); dead = 1; break; }
       }
       if (s.dbg) pacer.t_feed += __builtin_amdgcn_s_memtime() - t0;
       if (dead) break;                                // never start a unit on a state that is not there
@@ -498,7 +510,12 @@ __device__ __forceinline__ void spmm_walk_body(
     Meta mc, mn;
     mc.k = mn.k = 0; mc.w = mn.w = 0;
     unsigned off_c = 0, off_n = 0;                    // OFF32: byte offset of the neighbour's row; else its row number
-    int ring_failed = 0;                              // per lane group; made wave-uniform after every stage() call
+    // A chunk that never came (ring spin expired / workgroup aborting): the lane group carries on with neighbour 0
+    // and weight 0 until the unit's loop ends -- the loop itself must stay free of exits: the compiler rotates it so
+    // that the last row of a batch is consumed behind the first requests of the next one, and an exit test at the
+    // loop end forces a full `s_waitcnt vmcnt(0)` drain per batch (measured: 1.69 -> 2.33 ms per pass) -- and the
+    // wave leaves right behind the loop, before the rows are written or the step is reported.
+    int ring_failed = 0;                              // per lane group
     auto stage = [&](int jb, Meta& m, unsigned& off) {
       if ((jb % kFeedChunk) == 0) {                   // entering a chunk: earlier ones are read, this one must be there
         const int gs = seg_base + jb / kFeedChunk;
@@ -507,19 +524,19 @@ __device__ __forceinline__ void spmm_walk_body(
         while (lds_ld(feed_ready + bin) <= gs) {
           __builtin_amdgcn_s_sleep(1);
           if (lds_ld(&wg_abort)) { ring_failed = 1; break; }
-          if (++it > kWalkSpinRing) { walk_fail(s.err, &wg_abort, kWalkErrRing); ring_failed = 1; break; }
+          if (++it > kWalkSpinRing) { walk_fail(&wg_abort, kWalkErrRing); ring_failed = 1; break; }
         }
       }
       const int at = (seg_base * kFeedChunk + jb + l) % RING;
-      const int idw = ring[at];
+      const int idw = ring_failed ? 0 : ring[at];
       m.k = (int)((unsigned)idw >> kWalkKShift);
       off = OFF32 ? (unsigned)(idw & kWalkIdMask) * (unsigned)(F4 * 16) : (unsigned)(idw & kWalkIdMask);
       if constexpr (H1 && sizeof(T) == 4) m.w = __int_as_float(ring[RING + at]);
       else if constexpr (H1) m.w = *reinterpret_cast<const T*>(ring + RING + at * WS);
+      if constexpr (H1) m.w = ring_failed ? (T)0 : m.w;
     };
     if (j0 < total && j0 < j1) stage(j0, mc, off_c);
-    bool dead = __any(ring_failed) != 0;
-    for (int jb = j0; jb < j1 && !dead; jb += SB) {
+    for (int jb = j0; jb < j1; jb += SB) {
       if (jb < total) {
         static_for<SB>([&](auto uc) {
           constexpr int u = decltype(uc)::value;
@@ -545,9 +562,8 @@ __device__ __forceinline__ void spmm_walk_body(
         consume(x, mc, wv);
         mc = mn; off_c = off_n;
       }
-      if (((jb + SB) % kFeedChunk) == 0) dead = __any(ring_failed) != 0;   // a chunk that never came: leave before its ids are used
     }
-    if (dead) break;
+    if (__any(ring_failed)) break;                    // (see above) nothing of this unit leaves the wave
     row_change(-1);      // the last row becomes the pending one ...
     finish_pending();    // ... and is folded in: the bin's state is in LDS again
     if (sidx == s.steps - 1) {
@@ -576,6 +592,7 @@ __device__ __forceinline__ void spmm_walk_body(
     if ((threadIdx.x & (kWave - 1)) == 0 && !(s.fault == 2 && q == 0 && gstep == 0)) lds_st(quad_done + q, gstep + 1);
     pacer.signal_slot(q, gstep + 1);
   }
+  walk_report(s.err, &wg_abort);     // (the worker waves always get here: every spin of theirs polls the abort flag)
   pacer.report(s.dbg, t_start);
 }
 
