@@ -79,6 +79,7 @@ _SIGNATURES = {
     "graphop_gather_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_scatter_add_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_add_rows_unique": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],
+    "graphop_add_rows_grouped": [ctypes.c_int, _P, _P, _P, _P, _P, _c64, _c64, _c64, _P],
     "graphop_attention_workspace_bytes": [ctypes.c_int, ctypes.c_int] + [_c64] * 5 + [_P, _P, _P,
                                                                                        ctypes.POINTER(_c64)],
     "graphop_attention_backward_is_fused": [ctypes.c_int] + [_c64] * 5 + [_P, _P, _P, ctypes.POINTER(ctypes.c_int)],
@@ -512,6 +513,27 @@ def gather_rows(src, idx, out=None):
         check(lib().graphop_gather_rows(dtype_code(src), ptr(src), ptr(idx), ptr(out), idx.numel(),
                                         src.size(0), row, stream_of(src)))
     return out
+
+
+def group_rows(idx):
+    """Grouping of a row-index list for add_rows_grouped: (ptr, rows, pos) with rows = the distinct values of idx in
+    ascending order, pos[ptr[g]:ptr[g + 1]] = the positions of rows[g] in idx, in their original order (stable)."""
+    order = torch.argsort(idx, stable=True)
+    rows, counts = torch.unique_consecutive(idx[order], return_counts=True)
+    ptr_ = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=idx.device)
+    torch.cumsum(counts, 0, out=ptr_[1:])
+    return ptr_, rows.contiguous(), order.contiguous()
+
+
+def add_rows_grouped(dst, groups, src):
+    """dst[rows[g]] += sum of src[pos[p]] over the group's positions, one launch (include/graphop_hip.h:
+    graphop_add_rows_grouped); groups = group_rows(idx)."""
+    ptr_, rows, pos = groups
+    row = dst[0].numel() if dst.size(0) else 0
+    with torch.cuda.device(dst.device):
+        check(lib().graphop_add_rows_grouped(dtype_code(dst), ptr(src), ptr(ptr_), ptr(rows), ptr(pos), ptr(dst),
+                                             rows.numel(), dst.size(0), row, stream_of(dst)))
+    return dst
 
 
 def scatter_add_rows(dst, idx, src, unique_runs=None):

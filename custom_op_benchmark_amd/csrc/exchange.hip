@@ -51,6 +51,39 @@ __global__ __launch_bounds__(256) void k_add_rows_unique(const T* __restrict__ s
   }
 }
 
+// dst[rows[g], :] += sum over p in [ptr[g], ptr[g + 1]) of src[pos[p], :] -- the received rows grouped by the own row
+// they belong to (grouping built once per shard, dist.py): ONE launch for all peers instead of one plain-add launch
+// per peer, every own row read and written once however many peers it was served to, no atomics, and the
+// summation order (peer order) is fixed.  16-byte units, one lane per unit.
+__global__ __launch_bounds__(256) void k_add_rows_grouped16(const float4* __restrict__ src, const i64* __restrict__ ptr,
+                                                            const i64* __restrict__ rows, const i64* __restrict__ pos,
+                                                            float4* __restrict__ dst, i64 n_groups, i64 row16) {
+  const i64 total = n_groups * row16;
+  for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+    const i64 g = t / row16, c = t - g * row16;
+    float4* d = dst + rows[g] * row16 + c;
+    float4 acc = *d;
+    for (i64 p = ptr[g]; p < ptr[g + 1]; ++p) {
+      const float4 v = src[pos[p] * row16 + c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *d = acc;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_rows_grouped(const T* __restrict__ src, const i64* __restrict__ ptr,
+                                                          const i64* __restrict__ rows, const i64* __restrict__ pos,
+                                                          T* __restrict__ dst, i64 n_groups, i64 row_elems) {
+  const i64 total = n_groups * row_elems;
+  for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+    const i64 g = t / row_elems, c = t - g * row_elems;
+    T* d = dst + rows[g] * row_elems + c;
+    T acc = *d;
+    for (i64 p = ptr[g]; p < ptr[g + 1]; ++p) acc += src[pos[p] * row_elems + c];
+    *d = acc;
+  }
+}
+
 inline unsigned grid_of(i64 total) {
   i64 g = ceil_div(total > 0 ? total : 1, 256);
   return (unsigned)(g > 65536 ? 65536 : g);
@@ -103,6 +136,32 @@ int graphop_add_rows_unique(int dtype, const void* src, const int64_t* idx, void
   else
     hipLaunchKernelGGL((k_add_rows_unique<double>), dim3(grid_of(n_idx * row_elems)), dim3(256), 0, st,
                        (const double*)src, (const i64*)idx, (double*)dst, n_idx, row_elems);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
+
+int graphop_add_rows_grouped(int dtype, const void* src, const int64_t* grp_ptr, const int64_t* grp_rows,
+                             const int64_t* grp_pos, void* dst, int64_t n_groups, int64_t n_dst_rows,
+                             int64_t row_elems, void* stream) {
+  const char* fn = "add_rows_grouped";
+  GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
+  GO_CHECK_ARG(n_groups >= 0 && n_dst_rows >= 0 && row_elems >= 0, "%s: negative size", fn);
+  if (n_groups * row_elems == 0) return GRAPHOP_OK;
+  GO_PTR(fn, src); GO_PTR(fn, grp_ptr); GO_PTR(fn, grp_rows); GO_PTR(fn, grp_pos); GO_PTR(fn, dst);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof("halo_unpack_add", st, "k_add_rows_grouped");
+  const size_t row_bytes = esize(dtype) * (size_t)row_elems;
+  if (dtype == GRAPHOP_F32 && row_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+    const i64 row16 = (i64)(row_bytes / 16);
+    hipLaunchKernelGGL(k_add_rows_grouped16, dim3(grid_of(n_groups * row16)), dim3(256), 0, st, (const float4*)src,
+                       (const i64*)grp_ptr, (const i64*)grp_rows, (const i64*)grp_pos, (float4*)dst, n_groups, row16);
+  } else if (dtype == GRAPHOP_F32) {
+    hipLaunchKernelGGL((k_add_rows_grouped<float>), dim3(grid_of(n_groups * row_elems)), dim3(256), 0, st, (const float*)src,
+                       (const i64*)grp_ptr, (const i64*)grp_rows, (const i64*)grp_pos, (float*)dst, n_groups, row_elems);
+  } else {
+    hipLaunchKernelGGL((k_add_rows_grouped<double>), dim3(grid_of(n_groups * row_elems)), dim3(256), 0, st, (const double*)src,
+                       (const i64*)grp_ptr, (const i64*)grp_rows, (const i64*)grp_pos, (double*)dst, n_groups, row_elems);
+  }
   GO_LAUNCH_CHECK();
   return GRAPHOP_OK;
 }

@@ -193,6 +193,7 @@ class ShardedAttention:
             self._all_to_all(serve, need_local, send_counts, self.recv_counts)
         self.send_counts = send_counts
         self.serve_rows = serve                                # our rows, grouped by destination peer
+        self._serve_groups = None                              # (ptr, rows, pos) of serve_rows, for the HIP add-home kernel
 
     # ---- collectives ---------------------------------------------------------------------------
     def _exchange_counts(self, counts):
@@ -276,8 +277,11 @@ class ShardedAttention:
         """Partial gradient rows that came home += into the owners' rows (serve_rows may repeat)."""
         if dX_own.is_cuda and self.ops is None and dX_own.is_contiguous():
             from . import _lib
-            # the rows served to ONE peer are distinct (its halo ids are unique): one plain-add kernel per peer
-            _lib.scatter_add_rows(dX_own, self.serve_rows, recv, unique_runs=self.send_counts)
+            # received rows grouped by the own row they belong to (built once): one launch for all peers, every own
+            # row read and written once, no atomics, fixed summation order (round 3: one plain-add launch per peer)
+            if self._serve_groups is None:
+                self._serve_groups = _lib.group_rows(self.serve_rows)
+            _lib.add_rows_grouped(dX_own, self._serve_groups, recv)
         else:
             dX_own.index_add_(0, self.serve_rows, recv)
         return dX_own

@@ -371,6 +371,13 @@ GRAPHOP_API int graphop_add_rows_unique(int dtype, const void* src, const int64_
                             int64_t n_dst_rows, int64_t row_elems, void* stream);
 GRAPHOP_API int graphop_scatter_add_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
                              int64_t n_dst_rows, int64_t row_elems, void* stream);
+/* add_rows_grouped (ABI 6): the received rows grouped by the own row they belong to --
+ * dst[grp_rows[g], :] += sum over p in [grp_ptr[g], grp_ptr[g + 1]) of src[grp_pos[p], :] -- ONE launch for the
+ * rows of all peers (add_rows_unique needs one per peer), every own row read and written once, no atomics,
+ * fixed summation order.  grp_rows must hold distinct rows; the grouping is built once per shard (dist.py). */
+GRAPHOP_API int graphop_add_rows_grouped(int dtype, const void* src, const int64_t* grp_ptr, const int64_t* grp_rows,
+                             const int64_t* grp_pos, void* dst, int64_t n_groups, int64_t n_dst_rows,
+                             int64_t row_elems, void* stream);
 
 #ifdef __cplusplus
 }

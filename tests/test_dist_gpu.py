@@ -84,8 +84,11 @@ def test_pack_and_scatter_add_kernels(dev):
         assert torch.equal(got, X[idx])
         acc = torch.rand(shape, device=dev, generator=gen, dtype=dt)
         want = acc.clone().index_add_(0, idx, got)
+        acc2 = acc.clone()
         _lib.scatter_add_rows(acc, idx, got)
         torch.testing.assert_close(acc, want, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6)
+        _lib.add_rows_grouped(acc2, _lib.group_rows(idx), got)      # one launch, rows grouped by destination
+        torch.testing.assert_close(acc2, want, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6)
     assert _lib.gather_rows(X, idx[:0]).shape[0] == 0
 
 
