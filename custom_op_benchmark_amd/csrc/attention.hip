@@ -216,7 +216,14 @@ int graphop_attention_workspace_bytes(int dtype, int backward, int64_t n_edges, 
   GO_CHECK_ARG(n_edges >= 0 && n_q >= 0 && n_k >= 0 && h >= 1 && d >= 0, "%s: negative size", fn);
   const size_t es = esize(dtype);
   if (!backward) {
-    *bytes_out = (int64_t)SlowWs(nullptr, 2, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
+    size_t need = 0;
+    const int fw = (plan_r && n_edges * h > 0)
+                       ? attn_fwd_walk(plan_r, n_q, n_k, h, d, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                       (hipStream_t)stream, /*dry_run=*/true, &need)
+                       : 0;
+    if (fw < 0) return -fw;
+    // the one-pass forward only needs the piece records of shared rows; the composed forward keeps s and a here
+    *bytes_out = fw == 1 ? (int64_t)need : (int64_t)SlowWs(nullptr, 2, es, n_edges, h, soft_rows_of(plan_r, n_q)).total;
     return GRAPHOP_OK;
   }
   AttnFast af;
@@ -259,6 +266,23 @@ int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indp
   }
   const graphop_plan* pm = plan_matches_full(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                                              (const i64*)indices, n_chunks, n_edges) ? plan : nullptr;
+  // ONE walk-style pass where it applies (kernels_attn_walk.h): s and a never leave the chip; its workspace (piece
+  // records of the rows that bins share) is what graphop_attention_workspace_bytes reported for this call
+  if (pm && n_edges * h > 0) {
+    GO_PTR(fn, Q); GO_PTR(fn, K); GO_PTR(fn, V); GO_PTR(fn, o);
+    size_t need = 0;
+    const int ok = attn_fwd_walk(pm, n_q, n_k, h, d, dtype, Q, K, V, o, stats, nullptr, 0, st, /*dry_run=*/true, &need);
+    if (ok < 0) return -ok;
+    if (ok == 1) {
+      GO_CHECK_ARG(workspace != nullptr && (size_t)workspace_bytes >= need,
+                   "%s: workspace of %lld bytes needed (graphop_attention_workspace_bytes), got %lld", fn,
+                   (long long)need, (long long)workspace_bytes);
+      const int fw = attn_fwd_walk(pm, n_q, n_k, h, d, dtype, Q, K, V, o, stats, workspace, workspace_bytes, st,
+                                   /*dry_run=*/false, nullptr);
+      if (fw < 0) return -fw;
+      if (fw == 1) return GRAPHOP_OK;
+    }
+  }
   const i64 soft_rows = soft_rows_of(pm, n_q);
   SlowWs ws((char*)workspace, 2, es, n_edges, h, soft_rows);
   GO_CHECK_ARG(n_edges * h == 0 || (workspace != nullptr && (size_t)workspace_bytes >= ws.total),

@@ -130,7 +130,7 @@ struct Walk {
   int* ids = nullptr;     // [(k << kWalkKShift) | neighbour id]
   int* widx = nullptr;    // edge id per slot
   int* bin_pos = nullptr; // [bins * GW + 1] first slot of every lane group's run
-  int* bin_rows = nullptr;// [bins * K * GW] row id | (shared << 31), -1 = unused
+  int* bin_rows = nullptr;// [bins * K * GW] row id | (shared << 31) | (first piece of a shared row << 30), -1 = unused
   int* bin_cum = nullptr; // [bins * GW] slots in every lane group's run
   int* sync = nullptr;    // kWalkSyncRing sets of pacer counters of the walk kernels (a set is zeroed before the launch that takes it)
   long long sync_ints = 0;  // ints per set
@@ -140,6 +140,8 @@ struct Walk {
 };
 constexpr int kWalkSyncRing = 4;
 constexpr int kWalkK = 15;        // most rows per lane group: 15 x 256 B + a 1 KB ring, x 32 lane groups = 152 KB of a CU's 160 KB LDS
+constexpr int kWalkFirstPiece = 1 << 30;   // Walk::bin_rows: bit 31 = row shared with a neighbouring bin, bit 30 = its first piece
+constexpr int kWalkRowMask = (1 << 30) - 1;
 constexpr int kWalkKShift = 26;   // ids of a table < 4 GiB of >= 64-B rows need 26 bits; 6 bits of row-in-bin (<= 56)
 constexpr long long kLongSegment = 1024;   // rows above this many slots are listed for the workgroup-per-row softmax
 constexpr long long kLongSegmentBwd = 2048;  // ... which the backward uses only above this many (it caches 32 items per lane)

@@ -13,6 +13,7 @@
 #include "host.h"
 #include "kernels_fast.h"
 #include "kernels_walk.h"
+#include "kernels_attn_walk.h"
 #include "kernels_block.h"
 #include "kernels_attn.h"
 #include "kernels_generic.h"
@@ -406,7 +407,8 @@ struct WalkDebug {
 // table of n_table_rows rows, and fetch / build the layout.  1 = use it, 0 = no, < 0 = error (negated).
 // `K` = rows per lane group the kernel's LDS holds.
 template <int L, int NV>
-int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t st, WalkLaunch* out, bool dry_run = false) {
+int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t st, WalkLaunch* out, bool dry_run = false,
+                int tables = 1) {   // tables: gathered tables that must share an L2 window (the fused attention pass: K and V)
   if constexpr (NV != 1 || L < 16) {
     return 0;   // wider rows: kWalkK of them per lane group do not fit the LDS
   } else {
@@ -422,7 +424,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t s
     // column-major passes: 2 MB windows at 256-B rows (the scalar lines share the L2), 4 MB from 1-KB rows on
     // (Reddit-shape d = 256: 9.42 -> 8.83 ms; d = 128 is best at 2 MB)
     const i64 win_kb = pi.eid_identity ? t.walk_window_kb : (16LL * L * NV >= 1024 ? 2 * (i64)t.walk_window_kb_col : t.walk_window_kb_col);
-    i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes, (win_kb > 0 ? win_kb : 1) * 1024));
+    i64 W = t.sweep_w > 0 ? t.sweep_w : pow2ceil(ceil_div(table_bytes * tables, (win_kb > 0 ? win_kb : 1) * 1024));
     if (W < 2) W = 2;
     if (W > t.max_windows || W > 512) return 0;
     const i64 mean_row = pi.n_edges / pi.n_segments;
@@ -535,6 +537,69 @@ int try_spmm_walk(const char* tag, int dtype, const graphop_plan* plan, i64 n_ta
     return 1;
   }
 }
+
+}  // namespace
+
+// Fused attention forward as one walk-style pass (kernels_attn_walk.h): fp32, one head, d = 64, row-major plan with
+// identity eid, tables < 4 GiB.  Workspace: piece records of the rows that bins share + two n_q-sized merge arrays.
+int attn_fwd_walk(const graphop_plan* plan, i64 n_q, i64 n_k, i64 h, i64 d, int dtype, const void* Q, const void* K,
+                  const void* V, void* o, void* stats, void* ws, i64 ws_bytes, hipStream_t st, bool dry_run,
+                  size_t* ws_needed) {
+  constexpr int L = 16;
+  const Tuning& t = tuning();
+  if (ws_needed) *ws_needed = 0;
+  if (!t.attn_fwd_walk || !t.attn_fused || t.force_generic || dtype != GRAPHOP_F32 || h != 1 || d != 4 * L || !plan) return 0;
+  if (!plan->info.eid_identity || !(t.walk & 2) || !table_off32(n_k, L, 1)) return 0;
+  if (plan->info.max_row >= n_q || plan->info.max_index >= n_k) return 0;
+  constexpr int KR = attn_walk_rows<L>();
+  static_assert(KR >= 4, "rows per lane group of the fused forward");
+  WalkLaunch wl;
+  const int use = choose_walk<L, 1>(plan, n_k, KR, st, &wl, dry_run, /*tables=*/2);
+  if (use != 1) return use;
+  // one pacing step per window (the SpMM walk's two per window measured 1 % slower here: 11.93 vs 11.78 ms per fused step)
+  if (t.walk_steps > 1 && wl.view.steps >= 2 * t.walk_steps) wl.view.steps /= t.walk_steps;
+  const i64 bins = (i64)wl.view.groups * wl.view.rounds, np = 2 * bins, F = 4 * L;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_row = 0, o_ml = o_row + up(sizeof(int) * (size_t)np), o_po = o_ml + up(sizeof(float) * 2 * (size_t)np);
+  const size_t o_m = o_po + up(sizeof(float) * (size_t)(np * F)), o_l = o_m + up(sizeof(float) * (size_t)n_q);
+  const size_t need = o_l + up(sizeof(float) * (size_t)n_q);
+  if (ws_needed) *ws_needed = need;
+  if (dry_run) return 1;
+  if (!ws || (size_t)ws_bytes < need) return 0;    // (the caller sized the workspace for the composed path: always larger)
+  char* base = (char*)ws;
+  AttnWalkArgs a;
+  a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.o = (float*)o; a.stats = (float*)stats;
+  a.p_row = (int*)(base + o_row); a.p_ml = (float*)(base + o_ml); a.p_o = (float*)(base + o_po);
+  float* Mtmp = (float*)(base + o_m);
+  float* Ltmp = (float*)(base + o_l);
+  if (zero_async(o, sizeof(float) * (size_t)(n_q * F), st) != hipSuccess) return -GRAPHOP_ERR_HIP;
+  {
+    ProfScope prof("attn_fwd_setup", st, "k_fill");
+    const unsigned fb = (unsigned)(ceil_div(np > n_q ? np : n_q, 256) > 4096 ? 4096 : ceil_div(np > n_q ? np : n_q, 256));
+    hipLaunchKernelGGL((k_fill<int>), dim3(fb), dim3(256), 0, st, a.p_row, np, -1);
+    hipLaunchKernelGGL((k_fill<float>), dim3(fb), dim3(256), 0, st, Mtmp, n_q, kAttnNegBig);
+    hipLaunchKernelGGL((k_fill<float>), dim3(fb), dim3(256), 0, st, Ltmp, n_q, 0.f);
+  }
+  {
+    WalkDebug dbg;
+    dbg.arm(&wl, "attn_fwd", st, kWalkWorkers / kWave);
+    ProfScope prof("attn_fwd", st, "k_attn_fwd_walk_f32");
+    (void)hipFuncSetAttribute((const void*)k_attn_fwd_walk_f32<L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    const size_t lds_bytes = (size_t)(kWalkWorkers / L) * attn_walk_group_bytes<L>(KR);
+    hipLaunchKernelGGL((k_attn_fwd_walk_f32<L>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view, a);
+  }
+  {
+    ProfScope prof("attn_fwd_merge", st, "k_attn_piece_add");
+    hipLaunchKernelGGL(k_attn_piece_max, dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, st, a.p_row, a.p_ml, Mtmp, np);
+    const unsigned gb = (unsigned)ceil_div(np, kFastBlock / L);
+    hipLaunchKernelGGL((k_attn_piece_add<L>), dim3(gb), dim3(kFastBlock), 0, st, a.p_row, a.p_ml, a.p_o, Mtmp, Ltmp, a.o, np);
+    hipLaunchKernelGGL((k_attn_piece_fin<L>), dim3(gb), dim3(kFastBlock), 0, st, a.p_row, Mtmp, Ltmp, a.o, a.stats, np);
+  }
+  if (hipGetLastError() != hipSuccess) return -GRAPHOP_ERR_HIP;
+  return 1;
+}
+
+namespace {
 
 template <int L, int NV>
 int try_sddmm_sweep(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows, const void* A,
@@ -1029,7 +1094,7 @@ std::vector<TuneEntry> tune_table() {
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
-      {"attn_rows", &t.attn_rows}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
+      {"attn_rows", &t.attn_rows}, {"attn_fwd_walk", &t.attn_fwd_walk}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
       {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps}};
 }
@@ -1218,6 +1283,11 @@ int graphop_plan_prepare(graphop_plan_t* plan, int dtype, int64_t n_table_rows, 
     // (1) of the fused passes: same window geometry, but the piece length and the dealt id layout
     // differ with the resident grid of the pass
     rc = 0;
+    if (fused != 3) {   // the row-major side also serves the one-pass forward (kernels_attn_walk.h)
+      const int fw = attn_fwd_walk(plan, plan->info.max_row + 1, n_table_rows, h, d, dtype, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, 0, st, /*dry_run=*/true, nullptr);
+      if (fw < 0) return -fw;
+    }
     if (fused != 3) rc = attn_prepare_plan(plan, n_table_rows, d, false, st);
     if (rc >= 0 && fused != 2) rc = attn_prepare_plan(plan, n_table_rows, d, true, st);
     if (rc < 0) return -rc;

@@ -39,6 +39,7 @@ struct Tuning {
   int attn_bpc;           // resident workgroups per CU of the fused kernels
   int staged_ids;         // window-owner passes: plan-time deal + contiguous ids staged through LDS (IdStage);
                           // bit 0: SDDMM, bit 1: SpMM (both orientations), bit 2: the fused backward passes
+  int attn_fwd_walk;      // attention_forward as ONE walk-style pass (kernels_attn_walk.h) where it applies (fp32, h = 1, d = 64)
   int attn_max_d;         // widest row (floats) the fused window passes are chosen for: beyond 64 the two-row gathers
                           // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
@@ -72,6 +73,7 @@ struct Tuning {
     dense_min_fill = env_int("GRAPHOP_DENSE_MIN_FILL", 40);
     dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
     attn_fused = env_int("GRAPHOP_ATTN_FUSED", 1);
+    attn_fwd_walk = env_int("GRAPHOP_ATTN_FWD_WALK", 1);
     attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);
@@ -148,6 +150,12 @@ int plan_import_sweep(graphop_plan* p, int W, i64 win_cols, int T, int V, const 
 void plan_init_sweeps(graphop_plan*);
 // the fused attention passes' window structure for ONE orientation (attention.hip); dry run
 int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool col, hipStream_t st);
+
+// Fused attention forward on the walk (graphop_hip.hip; kernels_attn_walk.h): 1 = launched, 0 = does not apply,
+// < 0 = error (negated).  dry_run: only decide / build the layout and report the workspace it needs.
+int attn_fwd_walk(const graphop_plan* plan, i64 n_q, i64 n_k, i64 h, i64 d, int dtype, const void* Q, const void* K,
+                  const void* V, void* o, void* stats, void* ws, i64 ws_bytes, hipStream_t st, bool dry_run,
+                  size_t* ws_needed);
 
 int softmax_forward_stats(int dtype, const i64* row, const i64* indptr, const i64* eid, const void* x,
                           void* y, i64 C, i64 E, i64 h, void* ws, i64 ws_rows,

@@ -576,7 +576,7 @@ __device__ __forceinline__ void spmm_walk_body(
       for (int k = 0; k < K; ++k) {
         const int rec = __shfl(my_row, k, L);
         if (rec == -1) continue;   // group-uniform
-        const i64 row = rec & 0x7fffffff;
+        const i64 row = rec & kWalkRowMask;
         vec a[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) a[v] = accs[(k * NV + v) * L + l];

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256) void k_walk_fill(const i64* __restrict__ seg_e
       const i64 s = b.s0 + k;
       const i64 rs = seg_eptr[s], re = seg_eptr[s + 1];
       const bool shared = b.t0 > rs || b.t1 < re;
-      rec = (int)row[seg_chunk[s]] | (shared ? (int)0x80000000 : 0);
+      // bit 31: the row is shared with a neighbouring bin; bit 30: ... and this bin holds its FIRST piece
+      rec = (int)row[seg_chunk[s]] | (shared ? (int)0x80000000 : 0) | ((shared && b.t0 <= rs) ? kWalkFirstPiece : 0);
     }
     bin_rows[tb * kmax + k] = rec;
   }
@@ -883,7 +884,7 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
   const int kmax = K * GW;     // rows per wave bin
   const i64 waves = groups / GW;
   auto remember_unfit = [&]() { vec->push_back(wk); return GRAPHOP_OK; };
-  if (p->info.max_index >= (1LL << kWalkKShift) || S * (W + 1) >= (i64)1 << 40) return remember_unfit();
+  if (p->info.max_index >= (1LL << kWalkKShift) || S * (W + 1) >= (i64)1 << 40 || p->info.max_row >= kWalkRowMask) return remember_unfit();
   const i64* indptr = (const i64*)p->indptr;
   DevBuf seg_eptr, rw, len, ovf, tmp;
   GO_HIP(go_malloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1), st));

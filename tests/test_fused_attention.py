@@ -332,3 +332,71 @@ def test_fused_fuzz_shapes_and_paths(dev, seed):
                          attn_window_scale=2, attn_k=0, attn_bpc=0, touch_sddmm=1, attn_max_d=64, staged_ids=7).items():
             _lib.tune(k, v)
         _lib.clear_plan_cache()
+
+
+@pytest.fixture
+def force_fwd_walk():
+    _lib.tune_reset()
+    _lib.tune("sweep_min_kb", 0); _lib.tune("walk_window_kb", 8); _lib.tune("walk_window_kb_col", 8); _lib.tune("walk_min_bin", 0)
+    _lib.tune("sweep_min_granule", 0); _lib.tune("max_windows", 512); _lib.tune("window_kb", 4); _lib.tune("vrow_t", 64)
+    _lib.clear_plan_cache()
+    yield
+    _lib.tune_reset(); _lib.clear_plan_cache()
+
+
+@pytest.mark.parametrize("blocks", [8, 24, 0])
+@pytest.mark.parametrize("normal", [True, False])
+def test_fused_forward_is_one_walk_pass_vs_oracle(dev, force_fwd_walk, blocks, normal):
+    """attention_forward as ONE walk-style kernel (kernels_attn_walk.h: online softmax per (row, window) granule,
+    running output rows and (max, sum) in LDS, no s / a in the workspace) at a forced small geometry: rows cut by
+    bin boundaries (their pieces are merged by the three piece kernels), a hub row spanning many bins, empty rows,
+    empty windows, several rounds, padded last chunks; against the oracle's composition of the three primitives
+    (wrapper.py:20-30, 8-18, 44-55), and the backward (which recomputes from the statistics the forward left)."""
+    _lib.tune("walk_blocks", blocks)
+    g = random_graph(1500, 1541, 15000, seed=91 + blocks, chunk_size=32, zero_rows=0.15, hub=900)
+    inp = rand_inputs(g, 1, 64, seed=12, normal=normal)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"][:g.n_src])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V")] + [inp["dO"][:g.n_src].to(dev)]
+    _lib.profile_enable(True)
+    got = fused_step(gd, *args)
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    kern = {tag: r.get("kernel") for tag, r in prof.items()}
+    assert kern.get("attn_fwd") == "k_attn_fwd_walk_f32", kern
+    assert not ({"sddmm_fwd", "softmax_fwd", "spmm_fwd"} & set(kern)), kern          # nothing of the composed forward ran
+    close(got["o"], want["o"][:g.n_src])
+    for k in ("dQ", "dK", "dV"):
+        close(got[k], want[k])
+    # the statistics the forward leaves: (row maximum, 1 / sum) of the oracle's scores; rows without slots (0, 0)
+    a4 = (gd.row, gd.ptr_r, gd.eid_r, gd.indices_r)
+    o2, stats = ops.attention_forward(*a4, args[0], args[1], args[2])
+    s = want["s"]
+    deg = g.indptr_r[1:] - g.indptr_r[:-1]
+    rows = torch.repeat_interleave(torch.arange(g.n_src), deg)
+    m_ref = torch.full((g.n_src,), float("-inf")).scatter_reduce(0, rows, s, "amax", include_self=True)
+    l_ref = torch.zeros(g.n_src).index_add_(0, rows, torch.exp(s - m_ref[rows]))
+    has = deg > 0
+    st = stats.cpu().reshape(-1, 2)
+    torch.testing.assert_close(st[has, 0], m_ref[has], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st[has, 1], 1.0 / l_ref[has], rtol=1e-4, atol=1e-7)
+    assert (not (~has).any()) or float(st[~has].abs().max()) == 0.0
+    close(o2, want["o"][:g.n_src])
+
+
+def test_fused_forward_walk_matches_composed_forward_medium(dev, force_fwd_walk):
+    """Same inputs through the one-pass forward and through the composed forward (knob attn_fwd_walk = 0)."""
+    _lib.tune("walk_window_kb", 256); _lib.tune("window_kb", 256)
+    g = graphs.chung_lu_graph(20000, 1000000, alpha=0.6, seed=3).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    Q, K, V = (torch.randn(20000, 64, device=dev, generator=gen) / 4 for _ in range(3))
+    a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
+    tags = prof_tags(lambda: ops.attention_forward(*a4, Q, K, V))
+    assert "attn_fwd" in tags, tags
+    o1, st1 = ops.attention_forward(*a4, Q, K, V)
+    _lib.tune("attn_fwd_walk", 0)
+    tags = prof_tags(lambda: ops.attention_forward(*a4, Q, K, V))
+    assert "attn_fwd" not in tags and "sddmm_fwd" in tags, tags
+    o0, st0 = ops.attention_forward(*a4, Q, K, V)
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(st1, st0, rtol=1e-4, atol=1e-6)
