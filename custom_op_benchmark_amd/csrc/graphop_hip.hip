@@ -125,7 +125,7 @@ int* plan_take_queue(graphop_plan*, const Sweep*);
 int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
-int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**);
+int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**, bool want_widx = true);
 int plan_build_seg_eptr(graphop_plan*, hipStream_t);
 int* plan_take_walk_sync(graphop_plan*, const Walk*);
 
@@ -438,7 +438,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t s
     if (K < 1 || K > kWalkK) return 0;
     const Walk* wk = nullptr;
     const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, /*lane groups per bin=*/1, K,
-                                 slots, st, &wk);
+                                 slots, st, &wk, /*want_widx=*/tables == 1);
     if (rc != GRAPHOP_OK) return -rc;
     if (!wk) return 0;
     out->view.ids = wk->ids; out->view.widx = wk->widx; out->view.bin_pos = wk->bin_pos;

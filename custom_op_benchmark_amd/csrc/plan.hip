@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_walk_fill(const i64* __restrict__ seg_e
         for (int gg = 1; gg < GW; ++gg) g = p >= bnd[gg] ? gg : g;
         const int dst = base[g] + run[g] + (p - bnd[g]);
         ids[dst] = (int)(((unsigned)kk << kWalkKShift) | (unsigned)idx32[lo + i]);
-        widx[dst] = eid32 ? eid32[lo + i] : lo + i;
+        if (widx) widx[dst] = eid32 ? eid32[lo + i] : lo + i;
       }
     }
     for (int g = 0; g < GW; ++g) run[g] += bnd[g + 1] - bnd[g];
@@ -860,12 +860,13 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
 // (built once per geometry, kept with the plan).  *out = nullptr when the graph does not fit the
 // layout (a bin would hold more than K rows per lane group at every round count tried, sizes beyond 31 bits).
 int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int K, int xcd_slots, hipStream_t st,
-                  const Walk** out) {
+                  const Walk** out, bool want_widx) {   // want_widx = false: no edge-id run (the fused attention forward reads none)
   auto* vec = (std::vector<Walk>*)p->walks;
   std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
   *out = nullptr;
   for (auto& w : *vec)
-    if (w.W == W && w.win_cols == win_cols && w.groups == groups && w.GW == GW && w.K == K && w.xcd_slots == xcd_slots) {
+    if (w.W == W && w.win_cols == win_cols && w.groups == groups && w.GW == GW && w.K == K && w.xcd_slots == xcd_slots &&
+        (w.widx != nullptr || !want_widx || w.rounds == 0)) {
       if (w.rounds > 0) *out = &w;    // rounds == 0: remembered as "does not fit"
       return GRAPHOP_OK;
     }
@@ -963,7 +964,7 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
   const i64 steps = rounds * wk.max_steps;
   wk.sync_ints = 64LL * (8 + 16 * steps);   // one set of pacer counters; kWalkSyncRing of them are allocated
   if (go_malloc((void**)&wk.ids, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
-      go_malloc((void**)&wk.widx, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
+      (want_widx && go_malloc((void**)&wk.widx, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess) ||
       go_malloc((void**)&wk.bin_pos, sizeof(int) * (size_t)(gbins + 1), st) != hipSuccess ||
       go_malloc((void**)&wk.bin_rows, sizeof(int) * (size_t)(bins * kmax), st) != hipSuccess ||
       go_malloc((void**)&wk.bin_cum, sizeof(int) * (size_t)gbins, st) != hipSuccess ||
@@ -978,7 +979,7 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
   };
   if (hipMemcpyAsync(wk.bin_pos, len.p, sizeof(int) * (size_t)(gbins + 1), hipMemcpyDeviceToDevice, st) != hipSuccess ||
       hipMemsetAsync(wk.ids, 0, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess ||
-      hipMemsetAsync(wk.widx, 0, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess)
+      (wk.widx && hipMemsetAsync(wk.widx, 0, sizeof(int) * (size_t)wk.n_slots, st) != hipSuccess))
     return fail(GRAPHOP_ERR_HIP);
   hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)ceil_div(bins, 4)), dim3(256), 0, st, (const i64*)seg_eptr.p,
                      (const int*)rw.p, (const i64*)p->seg_chunk, (const i64*)p->row, (const int32_t*)p->idx32,
