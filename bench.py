@@ -274,8 +274,15 @@ def main():
         return torch.rand(shp(n), device=dev, generator=gen)
 
     Q = values(n_own).requires_grad_(True)
-    K = values(n_own).requires_grad_(True)
-    V = values(n_own).requires_grad_(True)
+    if runner is not None:
+        # the shard's K / V rows live in the own-row part of the runner's extended buffers (the halo rows land behind
+        # them): no n_own-row copy in front of every exchange
+        tail = (d,) if h == 1 else (h, d)
+        K = runner.own_rows_view("K", tail).copy_(values(n_own)).requires_grad_(True)
+        V = runner.own_rows_view("V", tail).copy_(values(n_own)).requires_grad_(True)
+    else:
+        K = values(n_own).requires_grad_(True)
+        V = values(n_own).requires_grad_(True)
     dO = values(n_own)
     torch.cuda.synchronize()
     t_graph = time.perf_counter() - t_setup

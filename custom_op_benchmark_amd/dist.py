@@ -255,7 +255,8 @@ class ShardedAttention:
         With async_op the exchange is only started: call wait() on the returned handle before the
         halo rows are read."""
         n_own = self.n_own
-        X_ext[:n_own].copy_(X_own)
+        if not (X_own.data_ptr() == X_ext.data_ptr() and X_own.is_contiguous()):
+            X_ext[:n_own].copy_(X_own)      # (no copy when the caller keeps its rows in the extended buffer: own_rows_view)
         send = self._pack(X_own, role)
         return self._timed("halo_" + role, lambda: self._all_to_all(X_ext[n_own:], send, self.recv_counts,
                                                                    self.send_counts, async_op))
@@ -303,6 +304,13 @@ class ShardedAttention:
         handle, recv = self.scatter_halo_grad_start(dX_own, dX_halo, role=role)
         handle.wait()
         return self._add_home(dX_own, recv)
+
+    def own_rows_view(self, name, shape_tail, dtype=torch.float32):
+        """The own-row part of the persistent extended buffer `name` ("K" / "V"): a caller that keeps its K / V rows
+        there (writes them into this view instead of a tensor of its own) saves the n_own-row copy in front of every
+        halo exchange -- step() recognises the view and only fetches the halo rows behind it."""
+        like = torch.empty((0,) + tuple(shape_tail), dtype=dtype, device=self.device)
+        return self._ext_buffer(name, like)[:self.n_own]
 
     def _ext_buffer(self, name, like):
         """Reusable (n_own + n_halo, ...) buffer keyed by role, shape tail and dtype."""

@@ -54,4 +54,7 @@ echo "[refresh] products done"
 # one-GPU rehearsal of rank 0's shard of the 8-way multi-GPU configs (timing only: exchanges = local copies)
 python bench.py --emulate-world 8 --graph papers100m --steps 5 --warmup 2 > "$OUT/${TAG}_emulate8_papers100m_bench.json" 2>/dev/null
 python bench.py --emulate-world 8 --graph rmat25 --steps 3 --warmup 1 > "$OUT/${TAG}_emulate8_rmat25_bench.json" 2>/dev/null
+# the REAL collective path on this one GPU (round 4): one-rank nccl (= RCCL) process group, self-halo, async all-to-alls
+python bench.py --gpus 1 --graph papers100m --rccl-self --steps 5 --warmup 2 > "$OUT/${TAG}_rccl_self_papers100m_bench.json" 2> "$OUT/${TAG}_rccl_self.err"
+python tools/time_fp64.py > "$OUT/${TAG}_fp64_timing.txt" 2>/dev/null
 echo "[refresh] all done"
