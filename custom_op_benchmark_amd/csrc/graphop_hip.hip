@@ -767,6 +767,41 @@ inline int try_spmm_block(const char* tag, int dtype, const graphop_plan* plan, 
   return 1;
 }
 
+// Will an SpMM-type pass over `plan` run on the chunk driver with row ownership, so that it can leave its output fully
+// defined itself (k_spmm_f32<..., SELFZERO>) and the caller may skip the zero fill?  Only for outputs large enough for
+// the fill to matter, fp32 lane-group shapes, sorted rows, and when neither the block-dense, the walk nor the
+// window-owner drivers take the pass (asked with dry runs: what they build is what the pass would have built).
+inline bool spmm_selfzero(int dtype, const i64* row, const i64* indptr, const i64* eid, const i64* indices, i64 C, i64 E,
+                          const graphop_plan* plan, i64 n_table_rows, const void* w, const void* X, const void* out,
+                          i64 h, i64 d, i64 n_out_rows, hipStream_t st) {
+  const Tuning& t = tuning();
+  if (!t.spmm_selfzero || C == 0 || !plan_matches_full(plan, row, indptr, eid, indices, C, E)) return false;
+  if (!plan->info.rows_sorted || !fast_ok(dtype, h, d, E, n_table_rows) || !aligned16(out)) return false;
+  if (plan->info.max_row >= n_out_rows) return false;
+  if ((double)n_out_rows * (double)(h * d) * 4.0 < (double)t.spmm_selfzero_min_mb * 1048576.0) return false;
+  if (spmm_block_applies(dtype, plan, n_table_rows, X, out, h, d)) return false;
+  int use = 0;
+  GO_DISPATCH_LNV((int)(h * d), {
+    if constexpr (NV == 1 && L >= 16) {
+      const int bit = plan->info.eid_identity ? 2 : 4;
+      const int K = spmm_walk_k<L, NV>(h, dtype);
+      if ((t.walk & bit) && K > 0 && (h == 1 || (table_off32(n_table_rows, L, NV) && aligned16(w)))) {
+        WalkLaunch wl;
+        use = choose_walk<L, NV>(plan, n_table_rows, K, st, &wl, /*dry_run=*/true);
+      }
+    }
+    if (use == 0) {
+      SweepLaunch sl;
+      SweepOpts so;
+      so.dry_run = 1;
+      so.bpc = sweep_bpc(NV, h == 1);
+      so.staged = spmm_staged(L, NV, h, n_table_rows);
+      use = choose_sweep(plan, n_table_rows, L, NV, st, &sl, /*accumulating=*/true, &so);
+    }
+  });
+  return use == 0;
+}
+
 // ---- launch helpers -------------------------------------------------------------------------------
 template <bool EDGE_B>
 int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
@@ -828,10 +863,31 @@ int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, 
 template <bool EDGE_X>
 int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
                 const i64* indices, const void* w, const void* X, void* out, i64 C, i64 E,
-                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st) {
+                i64 n_src_rows, i64 h, i64 d, const graphop_plan* plan, hipStream_t st, i64 selfzero_rows = -1) {
+  // selfzero_rows >= 0 (spmm_selfzero: the caller did NOT zero-fill `out`): straight to the self-zeroing chunk driver
   if (C == 0) return GRAPHOP_OK;
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   if constexpr (!EDGE_X) {
+    if (selfzero_rows >= 0) {
+      const int cpg = cpg_for(C, tuning().spmm_cpg, (int)(h * d));
+      const int F = (int)(h * d), d4 = (int)(d / 4);
+      ProfScope prof(tag, st, "k_spmm_f32");
+      GO_DISPATCH_LNV(F, {
+        const i64 groups = ceil_div(C, cpg);
+        if (groups > 1)
+          hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(blocks_for(groups - 1, kFastBlock / L)), dim3(kFastBlock), 0, st,
+                             row, (float*)out, C, cpg);
+        const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
+        if (h == 1)
+          hipLaunchKernelGGL((k_spmm_f32<L, NV, true, true, true>), dim3(nb), dim3(kFastBlock), 0, st, row, indptr, eid, indices,
+                             (const float*)w, (const float*)X, (float*)out, C, (int)h, d4, cpg, selfzero_rows);
+        else
+          hipLaunchKernelGGL((k_spmm_f32<L, NV, false, true, true>), dim3(nb), dim3(kFastBlock), 0, st, row, indptr, eid, indices,
+                             (const float*)w, (const float*)X, (float*)out, C, (int)h, d4, cpg, selfzero_rows);
+      });
+      GO_LAUNCH_CHECK();
+      return GRAPHOP_OK;
+    }
     if (try_spmm_block(tag, dtype, plan, n_src_rows, w, X, out, h, d, st)) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
   }
   // fp64 with a plan: the walk kernel at rows of 256 B - 1 KB (d = 32 / 64 / 128), else the generic kernels
@@ -1094,7 +1150,8 @@ std::vector<TuneEntry> tune_table() {
       {"dense_detect_min_fill", &t.dense_detect_min_fill},
       {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
-      {"attn_rows", &t.attn_rows}, {"attn_fwd_walk", &t.attn_fwd_walk}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
+      {"attn_rows", &t.attn_rows}, {"attn_fwd_walk", &t.attn_fwd_walk}, {"spmm_selfzero", &t.spmm_selfzero},
+      {"spmm_selfzero_min_mb", &t.spmm_selfzero_min_mb}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
       {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps}};
 }
@@ -1449,28 +1506,36 @@ int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* 
   }
   // an output whose orientation has no chunks may be NULL: that half of the op is skipped entirely
   // (the sharded step calls the op once per orientation to overlap the dK exchange, dist.py)
+  // (sz_*: the pass will run on the self-zeroing chunk driver, which leaves every output row defined: no fill)
+  bool sz_a = false, sz_b = false;
   if (n_a * h * d > 0 && !(dA == nullptr && n_row_chunks == 0)) {
     GO_PTR(fn, dA);
-    if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r,
-                               n_row_chunks, n_edges, plan_r, n_b, B, dA, h, d, n_a))
+    sz_a = dy != nullptr && B != nullptr &&
+           spmm_selfzero(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r, n_row_chunks,
+                         n_edges, plan_r, n_b, dy, B, dA, h, d, n_a, st);
+    if (!sz_a && !spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r, (const i64*)indices_r,
+                                        n_row_chunks, n_edges, plan_r, n_b, B, dA, h, d, n_a))
       GO_HIP(zero_async(dA, es * (size_t)(n_a * h * d), st));
   }
   if (n_b * h * d > 0 && !(dB == nullptr && n_col_chunks == 0)) {
     GO_PTR(fn, dB);
-    if (!spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c,
-                               n_col_chunks, n_edges, plan_c, n_a, A, dB, h, d, n_b))
+    sz_b = dy != nullptr && A != nullptr &&
+           spmm_selfzero(dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c, n_col_chunks,
+                         n_edges, plan_c, n_a, dy, A, dB, h, d, n_b, st);
+    if (!sz_b && !spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c, (const i64*)indices_c,
+                                        n_col_chunks, n_edges, plan_c, n_a, A, dB, h, d, n_b))
       GO_HIP(zero_async(dB, es * (size_t)(n_b * h * d), st));
   }
   if (h * d == 0) return GRAPHOP_OK;
   if (n_row_chunks > 0) {
     GO_PTR(fn, row); GO_PTR(fn, indptr_r); GO_PTR(fn, eid_r); GO_PTR(fn, indices_r); GO_PTR(fn, B); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dA", dtype, (const i64*)row, (const i64*)indptr_r, (const i64*)eid_r,
-                              (const i64*)indices_r, dy, B, dA, n_row_chunks, n_edges, n_b, h, d, plan_r, st));
+                              (const i64*)indices_r, dy, B, dA, n_row_chunks, n_edges, n_b, h, d, plan_r, st, sz_a ? n_a : -1));
   }
   if (n_col_chunks > 0) {
     GO_PTR(fn, col); GO_PTR(fn, indptr_c); GO_PTR(fn, eid_c); GO_PTR(fn, indices_c); GO_PTR(fn, A); GO_PTR(fn, dy);
     GO_TRY(launch_spmm<false>("sddmm_bwd_dB", dtype, (const i64*)col, (const i64*)indptr_c, (const i64*)eid_c,
-                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st));
+                              (const i64*)indices_c, dy, A, dB, n_col_chunks, n_edges, n_a, h, d, plan_c, st, sz_b ? n_b : -1));
   }
   return GRAPHOP_OK;
 }
@@ -1530,13 +1595,16 @@ int graphop_vector_spmm_forward(int dtype, const int64_t* row, const int64_t* in
   }
   if (n_y * h * d == 0) return GRAPHOP_OK;
   GO_PTR(fn, y);
-  if (!spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices,
-                             n_chunks, n_edges, plan, n_x, x, y, h, d, n_y))
+  const bool sz = edata != nullptr && x != nullptr &&
+                  spmm_selfzero(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices, n_chunks, n_edges,
+                                plan, n_x, edata, x, y, h, d, n_y, st);
+  if (!sz && !spmm_block_writes_all(dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices,
+                                    n_chunks, n_edges, plan, n_x, x, y, h, d, n_y))
     GO_HIP(zero_async(y, esize(dtype) * (size_t)(n_y * h * d), st));
   if (n_chunks == 0) return GRAPHOP_OK;
   GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, edata); GO_PTR(fn, x);
   return launch_spmm<false>("spmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
-                            (const i64*)indices, edata, x, y, n_chunks, n_edges, n_x, h, d, plan, st);
+                            (const i64*)indices, edata, x, y, n_chunks, n_edges, n_x, h, d, plan, st, sz ? n_y : -1);
 }
 
 int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* indptr,
@@ -1566,10 +1634,14 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
                          plan_r->info.indptr_monotone;
     if (!covered) GO_HIP(zero_async(dedata, es * (size_t)(n_edges * h), st));
   }
+  bool sz_x = false;
   if (n_x * h * d > 0) {
     GO_PTR(fn, dx);
-    if (!spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t,
-                               n_col_chunks, n_edges, plan_c, n_dy, dy, dx, h, d, n_x))
+    sz_x = edata != nullptr && dy != nullptr &&
+           spmm_selfzero(dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t, n_col_chunks,
+                         n_edges, plan_c, n_dy, edata, dy, dx, h, d, n_x, st);
+    if (!sz_x && !spmm_block_writes_all(dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t,
+                                        n_col_chunks, n_edges, plan_c, n_dy, dy, dx, h, d, n_x))
       GO_HIP(zero_async(dx, es * (size_t)(n_x * h * d), st));
   }
   if (h * d == 0) return GRAPHOP_OK;
@@ -1583,7 +1655,7 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     GO_PTR(fn, col); GO_PTR(fn, indptr_t); GO_PTR(fn, eid_t); GO_PTR(fn, indices_t); GO_PTR(fn, edata); GO_PTR(fn, dy);
     // kernel_1: dx = SpMM(edata, dy) over the column-major CSR, all C' chunks (:151-163)
     GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
-                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st));
+                              (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st, sz_x ? n_x : -1));
   }
   return GRAPHOP_OK;
 }

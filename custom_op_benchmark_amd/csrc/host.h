@@ -40,6 +40,9 @@ struct Tuning {
   int staged_ids;         // window-owner passes: plan-time deal + contiguous ids staged through LDS (IdStage);
                           // bit 0: SDDMM, bit 1: SpMM (both orientations), bit 2: the fused backward passes
   int attn_fwd_walk;      // attention_forward as ONE walk-style pass (kernels_attn_walk.h) where it applies (fp32, h = 1, d = 64)
+  int spmm_selfzero;      // SpMM-type passes on the chunk driver with row ownership leave their output fully defined
+                          // themselves (no zero fill by the entry point) ...
+  int spmm_selfzero_min_mb;  // ... for outputs of at least this many MB (below, the fill is noise)
   int attn_max_d;         // widest row (floats) the fused window passes are chosen for: beyond 64 the two-row gathers
                           // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
@@ -74,6 +77,8 @@ struct Tuning {
     dense_detect_min_fill = env_int("GRAPHOP_DENSE_DETECT_MIN_FILL", 10);
     attn_fused = env_int("GRAPHOP_ATTN_FUSED", 1);
     attn_fwd_walk = env_int("GRAPHOP_ATTN_FWD_WALK", 1);
+    spmm_selfzero = env_int("GRAPHOP_SPMM_SELFZERO", 1);
+    spmm_selfzero_min_mb = env_int("GRAPHOP_SPMM_SELFZERO_MIN_MB", 256);
     attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);

@@ -38,11 +38,33 @@ __global__ __launch_bounds__(kFastBlock) void k_sddmm_f32(
 // (the output is zero-filled beforehand either way).  Graphs of short rows -- one or two chunks per
 // row, tens of millions of rows: the sharded papers100M-shape columns -- otherwise pay one 4*F-byte
 // atomic flush per row at the memory-side atomic rate instead of a plain store.
-template <int L, int NV, bool H1, bool OWNED>
+// SELFZERO (with OWNED; round 4): the output arrives UNINITIALISED and this launch leaves every one of its n_out_rows
+// rows defined -- rows a group owns are stored whether or not they hold slots, the rows between two chunk rows (nodes
+// without edges) are zero-stored by the group that sees the gap (the one whose chunk follows it; the last group also
+// takes the rows behind the last chunk), and only the rows cut between two groups' chunk ranges (merged by atomics)
+// need zeros beforehand: k_zero_shared_rows, a few rows per group boundary.  The extended outputs of the sharded step
+// (29 M rows x 512 B on the papers100M-shape shard) otherwise pay a 14.8 GB zero fill per pass in front of stores that
+// overwrite nearly all of it.
+template <int L, int NV>
+__global__ __launch_bounds__(kFastBlock) void k_zero_shared_rows(const i64* __restrict__ row, float* __restrict__ out,
+                                                                 i64 n_chunks, int chunks_per_group) {
+  constexpr i64 F4 = (i64)L * NV;
+  const int l = threadIdx.x % L;
+  const i64 g = (i64)blockIdx.x * (kFastBlock / L) + threadIdx.x / L;     // boundary in front of group g + 1
+  const i64 c = (g + 1) * chunks_per_group;
+  if (c >= n_chunks) return;
+  const i64 r = row[c];
+  if (r != row[c - 1]) return;                       // the row is not cut by this boundary
+#pragma unroll
+  for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[r * F4 + v * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int L, int NV, bool H1, bool OWNED, bool SELFZERO = false>
 __global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
     const i64* __restrict__ row, const i64* __restrict__ indptr, const i64* __restrict__ eid,
     const i64* __restrict__ indices, const float* __restrict__ w, const float* __restrict__ X,
-    float* __restrict__ out, i64 n_chunks, int h, int d4, int chunks_per_group) {
+    float* __restrict__ out, i64 n_chunks, int h, int d4, int chunks_per_group, i64 n_out_rows = 0) {
+  static_assert(!SELFZERO || OWNED, "self-zeroing needs row ownership");
   constexpr i64 F4 = (i64)L * NV;
   const int l = threadIdx.x % L;
   const i64 gid = (i64)blockIdx.x * GroupCfg<L>::kGroupsPerBlock + threadIdx.x / L;
@@ -70,24 +92,33 @@ __global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
       atomic_flush<L, NV>(out, r, acc, l);
     }
   };
+  auto zero_rows = [&](i64 a, i64 b) {   // rows [a, b): nodes without edges
+    for (i64 g = a; g < b; ++g)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[g * F4 + v * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
   i64 cur_row = -1;
   bool dirty = false;
+  if constexpr (SELFZERO) zero_rows(row_before + 1, row[c0]);   // the gap in front of this group's first row (row_before = -1 for group 0)
   for (i64 c = c0; c < c1; ++c) {
     const i64 r = row[c];
     if (r != cur_row) {
-      if (dirty) {
+      // SELFZERO: an owned row is stored even when its chunks hold no slots (a shared one only adds, and only when dirty)
+      if (dirty || (SELFZERO && cur_row >= 0 && cur_row != row_before && cur_row != row_after)) {
         flush(cur_row);
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         dirty = false;
       }
+      if constexpr (SELFZERO) { if (cur_row >= 0) zero_rows(cur_row + 1, r); }
       cur_row = r;
     }
     const i64 j0 = indptr[c], j1 = indptr[c + 1];
     if (j1 > j0) dirty = true;
     spmm_range<L, NV, H1, false, false, i64>(acc, j0, j1, eid, indices, w, X, h, hv, l);
   }
-  if (dirty) flush(cur_row);
+  if (dirty || (SELFZERO && cur_row != row_before && cur_row != row_after)) flush(cur_row);
+  if constexpr (SELFZERO) { if (c1 == n_chunks) zero_rows(cur_row + 1, n_out_rows); }
 }
 
 }  // namespace graphop

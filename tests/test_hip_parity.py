@@ -615,6 +615,8 @@ def test_fuzz_shapes_and_paths(dev, seed):
             _lib.tune("walk_steps", int(rng.choice([1, 2, 3]))); _lib.tune("max_windows", 512)
         else:
             _lib.tune("walk", 0)
+    if np.random.RandomState(7000 + seed).rand() < 0.5:      # (own stream: the draws above keep their graphs per seed)
+        _lib.tune("spmm_selfzero_min_mb", 0); _lib.tune("spmm_cpg", int(np.random.RandomState(7100 + seed).choice([1, 4, 16])))
     _lib.clear_plan_cache()
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
@@ -747,3 +749,60 @@ def test_step_replays_from_a_captured_hip_graph(dev, shape):
     finally:
         _lib.tune_reset()
         _lib.clear_plan_cache()
+
+
+@pytest.mark.parametrize("h,d,cs", [(1, 64, 8), (1, 128, 32), (4, 16, 1), (1, 16, 32), (8, 128, 8)])
+def test_chunk_spmm_defines_every_output_row_without_a_zero_fill(dev, h, d, cs):
+    """Self-zeroing chunk driver (k_spmm_f32<..., SELFZERO>; csrc/kernels_chunk.h): with sorted rows the SpMM-type
+    passes leave EVERY output row defined -- owned rows stored, rows of nodes without edges zero-stored by the group
+    that sees the gap, rows cut between two groups zeroed by k_zero_shared_rows and merged by atomics -- so the entry
+    points skip the zero fill of large outputs (the extended tensors of the sharded step).  Outputs are handed over
+    full of NaNs through the C ABI; forward, dx, dA and dB against the oracle."""
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    _lib.tune("sweep", 0); _lib.tune("walk", 0); _lib.tune("spmm_selfzero_min_mb", 0); _lib.tune("spmm_cpg", 4)
+    try:
+        g = random_graph(700, 941, 9000, seed=3 + h + d, chunk_size=cs, zero_rows=0.3, hub=1500)
+        inp = rand_inputs(g, h, d, seed=5, normal=True)
+        gd = g.to(dev)
+        a8 = g.csr_args()
+        w = torch.rand(g.n_edges, h) if h > 1 else torch.rand(g.n_edges)
+        X = inp["K"]                                              # (n_dst, [h,] d)
+        dy = inp["dO"][:g.n_src]
+        want_y = oracle.vector_spmm_forward(*a8[:4], w, X)
+        want_dw, want_dx = oracle.vector_spmm_backward(*a8, w, torch.cat([dy, torch.zeros(g.n_dst - g.n_src, *dy.shape[1:])]), X)
+        want_dA, want_dB = oracle.maskedmm_csr_backward(*a8, inp["Q"], inp["K"], w)
+        L = _lib.lib()
+        wd, Xd, dyd, Qd = w.to(dev), X.to(dev), dy.to(dev).contiguous(), inp["Q"].to(dev)
+        nan = lambda *shape: torch.full(shape, float("nan"), device=dev)
+        tail = X.shape[1:]
+        with _lib.device_guard(dev):
+            pr = _lib.get_plan(gd.row, gd.ptr_r, gd.eid_r, gd.indices_r, g.n_dst)
+            pc = _lib.get_plan(gd.col, gd.ptr_c, gd.eid_c, gd.indices_c, g.n_src)
+            st = _lib.stream_of(Xd)
+            _lib.profile_enable(True)
+            y = nan(g.n_src, *tail)                               # n_y = n_src rows (the C ABI takes the row count)
+            _lib.check(L.graphop_vector_spmm_forward(_lib.dtype_code(Xd), _lib.ptr(gd.row), _lib.ptr(gd.ptr_r), _lib.ptr(gd.eid_r),
+                                                     _lib.ptr(gd.indices_r), _lib.ptr(wd), _lib.ptr(Xd), _lib.ptr(y), gd.row.size(0),
+                                                     g.n_edges, g.n_dst, g.n_src, h, d, pr.handle, st))
+            dw, dx = nan(*w.shape), nan(g.n_dst, *tail)
+            _lib.check(L.graphop_vector_spmm_backward(_lib.dtype_code(Xd), _lib.ptr(gd.row), _lib.ptr(gd.ptr_r), _lib.ptr(gd.eid_r),
+                                                      _lib.ptr(gd.indices_r), _lib.ptr(gd.col), _lib.ptr(gd.ptr_c), _lib.ptr(gd.eid_c),
+                                                      _lib.ptr(gd.indices_c), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(Xd), _lib.ptr(dw),
+                                                      _lib.ptr(dx), gd.row.size(0), gd.col.size(0), g.n_edges, g.n_dst, g.n_src, h, d,
+                                                      pr.handle, pc.handle, st))
+            dA, dB = nan(g.n_src, *tail), nan(g.n_dst, *tail)
+            _lib.check(L.graphop_maskedmm_csr_backward(_lib.dtype_code(Xd), _lib.ptr(gd.row), _lib.ptr(gd.ptr_r), _lib.ptr(gd.eid_r),
+                                                       _lib.ptr(gd.indices_r), _lib.ptr(gd.col), _lib.ptr(gd.ptr_c), _lib.ptr(gd.eid_c),
+                                                       _lib.ptr(gd.indices_c), _lib.ptr(Qd), _lib.ptr(Xd), _lib.ptr(wd), _lib.ptr(dA),
+                                                       _lib.ptr(dB), gd.row.size(0), gd.col.size(0), g.n_edges, g.n_src, g.n_dst, h, d,
+                                                       pr.handle, pc.handle, st))
+            torch.cuda.synchronize()
+            prof = _lib.profile_read()
+            _lib.profile_enable(False)
+        assert "zero_fill" not in prof, prof.keys()              # no output of these calls was zero-filled by the host
+        for got, want in ((y, want_y[:g.n_src]), (dx, want_dx), (dA, want_dA), (dB, want_dB)):
+            assert not torch.isnan(got).any()
+            close(got, want)
+        close(dw, want_dw)
+    finally:
+        _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()
