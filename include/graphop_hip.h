@@ -327,7 +327,10 @@ GRAPHOP_API int graphop_node_mul_edge_backward(int dtype, const int64_t* row, co
  *   backward: dQ, dK, dV for a given dO, from (Q, K, V, o, stats): a and ds are recomputed per slot
  *             (a = exp(s - m) / sum, ds = a (<dO_r, V_j> - <dO_r, o_r>)).
  * Results equal the composition of the unfused entry points up to fp32 summation order.
- * workspace: device scratch of graphop_attention_workspace_bytes(...) bytes (forward: s and a;
+ * Round 4: where it applies (fp32, h == 1, d == 64, a walkable row-major plan with identity eid) the forward is ONE
+ * kernel -- a walk-style pass with an online softmax (csrc/kernels_attn_walk.h) -- and s / a are never materialised.
+ * workspace: device scratch of graphop_attention_workspace_bytes(...) bytes (forward: piece records of the rows the
+ * walk's bins share, a few MB, for the one-pass form; s and a for the composed form;
  * backward: packed operand tables when the fused passes apply -- fp32, h == 1, both plans given;
  * window-owner drivers for sweepable plans and tables beyond the L2, chunk drivers otherwise --
  * else s, a, da, ds of the composed path). */
