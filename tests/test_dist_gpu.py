@@ -181,3 +181,22 @@ def test_rccl_path_at_world_size_one(dev):
     port = str(29500 + os.getpid() % 2000)
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD, port, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_line_through_the_rccl_path(dev):
+    """`bench.py --rccl-self` end to end on a small graph: one-rank nccl process group, self-halo, the JSON line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--graph", "custom", "--nodes", "30000",
+                        "--edges", "600000", "--d", "64", "--cut", "0.2", "--rccl-self", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--profile-steps", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["backend"] == "nccl" and cfg["world_size"] == 1 and cfg["halo"]["n_halo"] > 0
+    assert cfg["halo"]["exchange_ms_is_local_copy"] is False and set(cfg["halo"]["exchange_ms"]) == {"halo_K", "halo_V", "grad_dV", "grad_dK"}
+    assert line["value"] > 0 and line["n_gpus"] == 1
