@@ -159,3 +159,21 @@ def test_forced_collectives_at_world_size_one(tmp_path):
     tests/test_dist_gpu.py::test_rccl_path_at_world_size_one."""
     mp.spawn(_self_halo_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok"))
+
+
+def test_group_rows_matches_index_add():
+    """_lib.group_rows: the (ptr, rows, pos) grouping the HIP add-home kernel consumes (graphop_add_rows_grouped), checked
+    on CPU against index_add_: rows distinct and ascending, every position listed once, peer order kept inside a group."""
+    from custom_op_benchmark_amd import _lib
+    gen = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, 50, (400,), generator=gen)
+    ptr_, rows, pos = _lib.group_rows(idx)
+    assert torch.equal(rows, torch.unique(idx)) and int(ptr_[-1]) == idx.numel() and torch.equal(torch.sort(pos).values, torch.arange(400))
+    src = torch.rand(400, 3, generator=gen)
+    want = torch.zeros(50, 3).index_add_(0, idx, src)
+    got = torch.zeros(50, 3)
+    for g in range(rows.numel()):
+        p = pos[int(ptr_[g]):int(ptr_[g + 1])]
+        assert torch.all(idx[p] == rows[g]) and torch.all(p[1:] > p[:-1])      # stable: positions ascend inside a group
+        got[rows[g]] = src[p].sum(0)
+    torch.testing.assert_close(got, want)
