@@ -777,7 +777,7 @@ inline bool spmm_selfzero(int dtype, const i64* row, const i64* indptr, const i6
   const Tuning& t = tuning();
   if (!t.spmm_selfzero || C == 0 || !plan_matches_full(plan, row, indptr, eid, indices, C, E)) return false;
   if (!plan->info.rows_sorted || !fast_ok(dtype, h, d, E, n_table_rows) || !aligned16(out)) return false;
-  if (plan->info.max_row >= n_out_rows) return false;
+  if (plan->info.max_row >= n_out_rows || n_out_rows >= 0x7fffffffLL) return false;
   if ((double)n_out_rows * (double)(h * d) * 4.0 < (double)t.spmm_selfzero_min_mb * 1048576.0) return false;
   if (spmm_block_applies(dtype, plan, n_table_rows, X, out, h, d)) return false;
   int use = 0;

@@ -3,6 +3,7 @@
 // global_atomic_add_f32 (256 contiguous bytes per group); with a plan whose rows are sorted, rows owned by one
 // lane group are stored (OWNED).
 #pragma once
+#include <type_traits>
 #include "kernels_base.h"
 
 namespace graphop {
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(kFastBlock) void k_zero_shared_rows(const i64* __re
   for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[r * F4 + v * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// (compiled for five workgroups per CU at one float4 per lane: the chunk loops are chains of dependent loads, their rate
+// is resident waves x rows in flight; the self-zeroing form otherwise lands at 102 VGPRs = four)
 template <int L, int NV, bool H1, bool OWNED, bool SELFZERO = false>
-__global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
+__global__ __launch_bounds__(kFastBlock, NV == 1 ? 5 : 1) void k_spmm_f32(
     const i64* __restrict__ row, const i64* __restrict__ indptr, const i64* __restrict__ eid,
     const i64* __restrict__ indices, const float* __restrict__ w, const float* __restrict__ X,
     float* __restrict__ out, i64 n_chunks, int h, int d4, int chunks_per_group, i64 n_out_rows = 0) {
@@ -78,47 +81,52 @@ __global__ __launch_bounds__(kFastBlock) void k_spmm_f32(
   float4 acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // rows shared with the neighbouring groups (only these need atomics when OWNED)
-  i64 row_before = -1, row_after = -1;
+  // rows shared with the neighbouring groups (only these need atomics when OWNED).  (Row ids as 32-bit values in the
+  // self-zeroing form -- its host predicate admits outputs below 2^31 rows only -- : the extra bookkeeping then fits
+  // the register budget of five workgroups per CU.)
+  using RT = typename std::conditional<SELFZERO, int, i64>::type;
+  RT row_before = -1, row_after = -1;
   if constexpr (OWNED) {
-    if (c0 > 0) row_before = row[c0 - 1];
-    if (c1 < n_chunks) row_after = row[c1];
+    if (c0 > 0) row_before = (RT)row[c0 - 1];
+    if (c1 < n_chunks) row_after = (RT)row[c1];
   }
-  auto flush = [&](i64 r) {
+  auto flush = [&](RT r) {
     if (OWNED && r != row_before && r != row_after) {
 #pragma unroll
-      for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[r * F4 + v * L + l] = acc[v];
+      for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[(i64)r * F4 + v * L + l] = acc[v];
     } else {
-      atomic_flush<L, NV>(out, r, acc, l);
+      atomic_flush<L, NV>(out, (i64)r, acc, l);
     }
   };
-  auto zero_rows = [&](i64 a, i64 b) {   // rows [a, b): nodes without edges
-    for (i64 g = a; g < b; ++g)
+  auto zero_rows = [&](RT a, RT b) {   // rows [a, b): nodes without edges
+    for (RT g = a; g < b; ++g)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[g * F4 + v * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int v = 0; v < NV; ++v) reinterpret_cast<float4*>(out)[(i64)g * F4 + v * L + l] = make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  i64 cur_row = -1;
-  bool dirty = false;
-  if constexpr (SELFZERO) zero_rows(row_before + 1, row[c0]);   // the gap in front of this group's first row (row_before = -1 for group 0)
+  // SELFZERO: `cur_row` starts at the row in front of this group's chunks (-1 for group 0), so the first row change also
+  // zero-stores the gap in front of the group's first row; it never flushes that foreign row (`mine` is false until then)
+  RT cur_row = SELFZERO ? row_before : (RT)-1;
+  bool dirty = false, mine = false;
   for (i64 c = c0; c < c1; ++c) {
-    const i64 r = row[c];
-    if (r != cur_row) {
+    const RT r = (RT)row[c];
+    if (r != cur_row || (SELFZERO && !mine)) {
       // SELFZERO: an owned row is stored even when its chunks hold no slots (a shared one only adds, and only when dirty)
-      if (dirty || (SELFZERO && cur_row >= 0 && cur_row != row_before && cur_row != row_after)) {
+      if (dirty || (SELFZERO && mine && cur_row != row_before && cur_row != row_after)) {
         flush(cur_row);
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         dirty = false;
       }
-      if constexpr (SELFZERO) { if (cur_row >= 0) zero_rows(cur_row + 1, r); }
+      if constexpr (SELFZERO) zero_rows(cur_row + 1, r);
       cur_row = r;
+      mine = true;
     }
     const i64 j0 = indptr[c], j1 = indptr[c + 1];
     if (j1 > j0) dirty = true;
     spmm_range<L, NV, H1, false, false, i64>(acc, j0, j1, eid, indices, w, X, h, hv, l);
   }
   if (dirty || (SELFZERO && cur_row != row_before && cur_row != row_after)) flush(cur_row);
-  if constexpr (SELFZERO) { if (c1 == n_chunks) zero_rows(cur_row + 1, n_out_rows); }
+  if constexpr (SELFZERO) { if (c1 == n_chunks) zero_rows(cur_row + 1, (RT)n_out_rows); }
 }
 
 }  // namespace graphop
