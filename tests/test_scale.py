@@ -93,6 +93,8 @@ def test_reddit_scale_fused_equals_unfused(dev):
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     assert prof["attn_bwd_row"]["kernel"] == "k_attn_bwd_wown_f32" and "attn_bwd_col" in prof, prof
+    # the forward ran as ONE walk-style pass (no SDDMM / softmax / SpMM launches of the composition)
+    assert prof["attn_fwd"]["kernel"] == "k_attn_fwd_walk_f32" and not ({"sddmm_fwd", "softmax_fwd", "spmm_fwd"} & set(prof)), prof
     tol = dict(rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(o2.detach(), o.detach(), **tol)
     torch.testing.assert_close(q2.grad, q.grad, **tol)
