@@ -186,7 +186,7 @@ int check_async_error() {
   const char* what = code == kWalkErrQuad ? "a (step, quad) unit waited for its quad's previous step"
                    : code == kWalkErrRing ? "a worker wave waited for a ring chunk of its feeder wave"
                    : "unknown code";
-  set_error("a walk kernel (k_spmm_walk_f32) of an earlier launch aborted: %s until its spin bound expired (device "
+  set_error("a walk kernel (k_spmm_walk_* / k_attn_fwd_walk_f32) of an earlier launch aborted: %s until its spin bound expired (device "
             "error code %d); the outputs of that launch are invalid", what, code);
   return GRAPHOP_ERR_HIP;
 }
@@ -355,6 +355,16 @@ inline bool spmm_staged(int L, int NV, i64 h, i64 n_table_rows) {
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // ---- walk drivers (kernels_walk.h) -----------------------------------------------------------------
+// The walk kernels take nearly all of a CU's LDS as dynamic shared memory: the limit is raised once per kernel function.
+inline void allow_full_lds(const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;   // (per device: function attributes are)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert({dev, fn}).second)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
 struct WalkLaunch {
   WalkView view;
   unsigned blocks;
@@ -497,8 +507,7 @@ int try_spmm_walk(const char* tag, int dtype, const graphop_plan* plan, i64 n_ta
     dbg.arm(&wl, tag, st, kWalkWorkers / kWave);
     ProfScope prof(tag, st, dtype == GRAPHOP_F64 ? "k_spmm_walk_f64" : "k_spmm_walk_f32");
     auto launch = [&](auto kfn, size_t lds_bytes, auto... args) {
-      // (the attribute is per kernel function: set it on every launch path once)
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      allow_full_lds((const void*)kfn);
       if (tuning().walk_debug) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kfn, kWalkThreads, lds_bytes);
@@ -584,7 +593,7 @@ int attn_fwd_walk(const graphop_plan* plan, i64 n_q, i64 n_k, i64 h, i64 d, int 
     WalkDebug dbg;
     dbg.arm(&wl, "attn_fwd", st, kWalkWorkers / kWave);
     ProfScope prof("attn_fwd", st, "k_attn_fwd_walk_f32");
-    (void)hipFuncSetAttribute((const void*)k_attn_fwd_walk_f32<L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    allow_full_lds((const void*)k_attn_fwd_walk_f32<L>);
     const size_t lds_bytes = (size_t)(kWalkWorkers / L) * attn_walk_group_bytes<L>(KR);
     hipLaunchKernelGGL((k_attn_fwd_walk_f32<L>), dim3(wl.blocks), dim3(kWalkThreads), lds_bytes, st, wl.view, a);
   }
