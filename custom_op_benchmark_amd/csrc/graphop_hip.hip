@@ -811,6 +811,16 @@ inline bool spmm_selfzero(int dtype, const i64* row, const i64* indptr, const i6
   return use == 0;
 }
 
+// The slot-walking form of the row-owning chunk driver (k_spmm_flat_f32): one head, one float4 per lane (d = 64 / 128 / 256),
+// chosen where the chunks are short on average (the extended column side of a node-range shard: 6.8 slots per chunk, half
+// of the chunks with one or two) -- at 13+ slots per chunk the per-chunk loop is within 6 % of the random-row rate already.
+inline bool spmm_flat(i64 C, i64 E, i64 h, i64 d) {
+  const Tuning& t = tuning();
+  if (!t.spmm_flat || h != 1 || (d != 64 && d != 128 && d != 256) || C == 0) return false;
+  // (small graphs are launch-bound and its longer prologue shows: Cora-shape passes 6.5 -> 9.1 us)
+  return E < (i64)t.spmm_flat_max_mean * C && C >= (i64)t.spmm_flat_min_chunks;
+}
+
 // ---- launch helpers -------------------------------------------------------------------------------
 template <bool EDGE_B>
 int launch_sddmm(const char* tag, int dtype, const i64* row, const i64* indptr, const i64* eid,
@@ -878,15 +888,24 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
   if (!plan_matches_full(plan, row, indptr, eid, indices, C, E)) plan = nullptr;
   if constexpr (!EDGE_X) {
     if (selfzero_rows >= 0) {
-      const int cpg = cpg_for(C, tuning().spmm_cpg, (int)(h * d));
+      const bool flat = spmm_flat(C, E, h, d);
+      const int cpg = cpg_for(C, flat ? tuning().spmm_flat_cpg : tuning().spmm_cpg, (int)(h * d));
       const int F = (int)(h * d), d4 = (int)(d / 4);
-      ProfScope prof(tag, st, "k_spmm_f32");
+      ProfScope prof(tag, st, flat ? "k_spmm_flat_f32" : "k_spmm_f32");
       GO_DISPATCH_LNV(F, {
         const i64 groups = ceil_div(C, cpg);
         if (groups > 1)
           hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(blocks_for(groups - 1, kFastBlock / L)), dim3(kFastBlock), 0, st,
                              row, (float*)out, C, cpg);
         const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
+        if constexpr (NV == 1 && L >= 16) {
+          if (flat) {
+            hipLaunchKernelGGL((k_spmm_flat_f32<L, true>), dim3(nb), dim3(kFastBlock), 0, st, row, indptr, eid, indices,
+                               (const float*)w, (const float*)X, (float*)out, C, cpg, selfzero_rows);
+            GO_LAUNCH_CHECK();
+            return GRAPHOP_OK;
+          }
+        }
         if (h == 1)
           hipLaunchKernelGGL((k_spmm_f32<L, NV, true, true, true>), dim3(nb), dim3(kFastBlock), 0, st, row, indptr, eid, indices,
                              (const float*)w, (const float*)X, (float*)out, C, (int)h, d4, cpg, selfzero_rows);
@@ -920,12 +939,26 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
       if (use < 0) return -use;
       if (use == 1) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
     }
+    // plan.rows_sorted: a row's chunks are adjacent, rows inside one group's range need no atomics
+    const bool owned = plan && plan->info.rows_sorted && ((uintptr_t)out & 15) == 0;
+    if (owned && spmm_flat(C, E, h, d)) {      // short chunks: the slot-walking form of the same driver
+      int done = 0;
+      const int fcpg = cpg_for(C, tuning().spmm_flat_cpg, (int)(h * d));
+      ProfScope prof(tag, st, "k_spmm_flat_f32");
+      GO_DISPATCH_LNV(F, {
+        if constexpr (NV == 1 && L >= 16) {
+          const unsigned nb = blocks_for(ceil_div(C, fcpg), GroupCfg<L>::kGroupsPerBlock);
+          hipLaunchKernelGGL((k_spmm_flat_f32<L, false>), dim3(nb), dim3(kFastBlock), 0, st, row, indptr, eid, indices,
+                             (const float*)w, (const float*)X, (float*)out, C, fcpg, (i64)0);
+          done = 1;
+        }
+      });
+      if (done) { GO_LAUNCH_CHECK(); return GRAPHOP_OK; }
+    }
     ProfScope prof(tag, st, "k_spmm_f32");
     GO_DISPATCH_LNV(F, {
       const i64 groups = ceil_div(C, cpg);
       const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
-      // plan.rows_sorted: a row's chunks are adjacent, rows inside one group's range need no atomics
-      const bool owned = plan && plan->info.rows_sorted && ((uintptr_t)out & 15) == 0;
       auto go = [&](auto h1, auto ow) {
         hipLaunchKernelGGL((k_spmm_f32<L, NV, decltype(h1)::value, decltype(ow)::value>), dim3(nb),
                            dim3(kFastBlock), 0, st, row, indptr, eid, indices, (const float*)w,
@@ -1160,7 +1193,9 @@ std::vector<TuneEntry> tune_table() {
       {"attn_fused", &t.attn_fused},
       {"attn_window_scale", &t.attn_window_scale}, {"attn_k", &t.attn_k}, {"attn_bpc", &t.attn_bpc},
       {"attn_rows", &t.attn_rows}, {"attn_fwd_walk", &t.attn_fwd_walk}, {"spmm_selfzero", &t.spmm_selfzero},
-      {"spmm_selfzero_min_mb", &t.spmm_selfzero_min_mb}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
+      {"spmm_selfzero_min_mb", &t.spmm_selfzero_min_mb}, {"spmm_flat", &t.spmm_flat},
+      {"spmm_flat_cpg", &t.spmm_flat_cpg}, {"spmm_flat_max_mean", &t.spmm_flat_max_mean},
+      {"spmm_flat_min_chunks", &t.spmm_flat_min_chunks}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
       {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps}};
 }

@@ -43,6 +43,10 @@ struct Tuning {
   int spmm_selfzero;      // SpMM-type passes on the chunk driver with row ownership leave their output fully defined
                           // themselves (no zero fill by the entry point) ...
   int spmm_selfzero_min_mb;  // ... for outputs of at least this many MB (below, the fill is noise)
+  int spmm_flat;          // row-owning chunk driver in its slot-walking form (k_spmm_flat_f32) where chunks are short ...
+  int spmm_flat_max_mean; // ... i.e. below this many slots per chunk on average
+  int spmm_flat_cpg;      // chunks per lane group of that form (more than spmm_cpg: a group should see several id batches)
+  int spmm_flat_min_chunks;  // ... and only for chunk lists at least this long
   int attn_max_d;         // widest row (floats) the fused window passes are chosen for: beyond 64 the two-row gathers
                           // dominate and the passes measure slower than the unfused ones (d=128: 18.9 vs 16.8 ms)
   int attn_rows;          // chunk-driver fused backward: -1 = by the cost rule, 0 = never, 1 = whenever legal
@@ -79,6 +83,11 @@ struct Tuning {
     attn_fwd_walk = env_int("GRAPHOP_ATTN_FWD_WALK", 1);
     spmm_selfzero = env_int("GRAPHOP_SPMM_SELFZERO", 1);
     spmm_selfzero_min_mb = env_int("GRAPHOP_SPMM_SELFZERO_MIN_MB", 256);
+    spmm_flat = env_int("GRAPHOP_SPMM_FLAT", 1);
+    spmm_flat_max_mean = env_int("GRAPHOP_SPMM_FLAT_MAX_MEAN", 10);
+    spmm_flat_cpg = env_int("GRAPHOP_SPMM_FLAT_CPG", 32);
+    if (spmm_flat_cpg < 1) spmm_flat_cpg = 1;
+    spmm_flat_min_chunks = env_int("GRAPHOP_SPMM_FLAT_MIN_CHUNKS", 1 << 20);
     attn_window_scale = env_int("GRAPHOP_ATTN_WINDOW_SCALE", 2);
     attn_k = env_int("GRAPHOP_ATTN_K", 0);
     attn_bpc = env_int("GRAPHOP_ATTN_BPC", 0);

@@ -617,6 +617,8 @@ def test_fuzz_shapes_and_paths(dev, seed):
             _lib.tune("walk", 0)
     if np.random.RandomState(7000 + seed).rand() < 0.5:      # (own stream: the draws above keep their graphs per seed)
         _lib.tune("spmm_selfzero_min_mb", 0); _lib.tune("spmm_cpg", int(np.random.RandomState(7100 + seed).choice([1, 4, 16])))
+    _lib.tune("spmm_flat_cpg", int(np.random.RandomState(7200 + seed).choice([2, 16, 128])))   # (slot-walking chunk driver)
+    _lib.tune("spmm_flat_min_chunks", 0)
     _lib.clear_plan_cache()
     try:
         g = random_graph(n_src, n_dst, n_edges, seed=seed, chunk_size=cs, zero_rows=float(rng.choice([0, 0.2])),
@@ -806,5 +808,105 @@ def test_chunk_spmm_defines_every_output_row_without_a_zero_fill(dev, h, d, cs):
             assert not torch.isnan(got).any()
             close(got, want)
         close(dw, want_dw)
+    finally:
+        _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()
+
+
+def _spmm_fwd_and_dx_through_the_abi(dev, g, gd, w, X, dy, h, d):
+    """vector_spmm_forward + backward through the C ABI into NaN-filled outputs; -> (y, dw, dx, profile)."""
+    L = _lib.lib()
+    wd, Xd, dyd = w.to(dev), X.to(dev), dy.to(dev).contiguous()
+    nan = lambda *shape: torch.full(shape, float("nan"), device=dev)
+    tail = X.shape[1:]
+    with _lib.device_guard(dev):
+        pr = _lib.get_plan(gd.row, gd.ptr_r, gd.eid_r, gd.indices_r, g.n_dst)
+        pc = _lib.get_plan(gd.col, gd.ptr_c, gd.eid_c, gd.indices_c, g.n_src)
+        st = _lib.stream_of(Xd)
+        _lib.profile_enable(True)
+        y = nan(g.n_src, *tail)
+        _lib.check(L.graphop_vector_spmm_forward(_lib.dtype_code(Xd), _lib.ptr(gd.row), _lib.ptr(gd.ptr_r), _lib.ptr(gd.eid_r),
+                                                 _lib.ptr(gd.indices_r), _lib.ptr(wd), _lib.ptr(Xd), _lib.ptr(y), gd.row.size(0),
+                                                 g.n_edges, g.n_dst, g.n_src, h, d, pr.handle, st))
+        dw, dx = nan(*w.shape), nan(g.n_dst, *tail)
+        _lib.check(L.graphop_vector_spmm_backward(_lib.dtype_code(Xd), _lib.ptr(gd.row), _lib.ptr(gd.ptr_r), _lib.ptr(gd.eid_r),
+                                                  _lib.ptr(gd.indices_r), _lib.ptr(gd.col), _lib.ptr(gd.ptr_c), _lib.ptr(gd.eid_c),
+                                                  _lib.ptr(gd.indices_c), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(Xd), _lib.ptr(dw),
+                                                  _lib.ptr(dx), gd.row.size(0), gd.col.size(0), g.n_edges, g.n_dst, g.n_src, h, d,
+                                                  pr.handle, pc.handle, st))
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+    return y, dw, dx, prof
+
+
+@pytest.mark.parametrize("selfzero", [1, 0])
+@pytest.mark.parametrize("d,cs,fcpg", [(64, 1, 3), (64, 32, 40), (128, 2, 150), (128, 32, 3), (256, 1, 70), (256, 32, 128),
+                                       (128, 1, 33)])
+def test_flat_chunk_spmm_short_rows_vs_oracle(dev, d, cs, fcpg, selfzero):
+    """Slot-walking form of the row-owning chunk driver (k_spmm_flat_f32, csrc/kernels_chunk.h; chosen below 10 slots per
+    chunk: the extended column side of a node-range shard).  Rows of 0-3 slots, a third of the rows empty, one hub row
+    cut into many chunks (and, at small chunks-per-group, between many lane groups: the atomic merge of shared rows),
+    chunks-per-group below and above the 2 L chunks of metadata a group keeps in registers; with and without the
+    self-zeroing rule (outputs arrive full of NaNs either way).  Semantics: graphop_kernel.cu:118-130 (forward),
+    :135-163 (backward)."""
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    _lib.tune("sweep", 0); _lib.tune("walk", 0); _lib.tune("dense_blocks", 0)
+    _lib.tune("spmm_selfzero_min_mb", 0 if selfzero else 1 << 20); _lib.tune("spmm_flat_cpg", fcpg)
+    _lib.tune("spmm_flat_min_chunks", 0)
+    try:
+        g = random_graph(2500, 3000, 6000, seed=11 + d + cs, chunk_size=cs, zero_rows=0.3, hub=300)
+        assert g.n_edges < 10 * g.row.numel()                      # the predicate of the flat form
+        inp = rand_inputs(g, 1, d, seed=5, normal=True)
+        w, X, dy = torch.rand(g.n_edges), inp["K"], inp["dO"][:g.n_src]
+        a8 = g.csr_args()
+        want_y = oracle.vector_spmm_forward(*a8[:4], w, X)[:g.n_src]
+        want_dw, want_dx = oracle.vector_spmm_backward(*a8, w, torch.cat([dy, torch.zeros(g.n_dst - g.n_src, d)]), X)
+        y, dw, dx, prof = _spmm_fwd_and_dx_through_the_abi(dev, g, g.to(dev), w, X, dy, 1, d)
+        assert prof["spmm_fwd"]["kernel"] == "k_spmm_flat_f32" and prof["spmm_bwd_dx"]["kernel"] == "k_spmm_flat_f32", prof
+        for got, want in ((y, want_y), (dx, want_dx), (dw, want_dw)):
+            assert not torch.isnan(got).any()
+            close(got, want)
+        _lib.tune("spmm_flat", 0)                                  # and the per-chunk loop it replaces, same inputs
+        _lib.clear_plan_cache()
+        y2, dw2, dx2, prof2 = _spmm_fwd_and_dx_through_the_abi(dev, g, g.to(dev), w, X, dy, 1, d)
+        assert prof2["spmm_fwd"]["kernel"] == "k_spmm_f32", prof2
+        torch.testing.assert_close(y, y2, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dx, dx2, rtol=1e-4, atol=1e-5)
+    finally:
+        _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()
+
+
+@pytest.mark.parametrize("fcpg", [1, 2, 5, 64])
+def test_flat_chunk_spmm_empty_chunks_and_gaps(dev, fcpg):
+    """A hand-made chunk list for the slot-walking driver: chunks without slots at the start, in the middle and at the end
+    of the list (the reference's kernel simply runs zero iterations for them, graphop_kernel.cu:121), rows without
+    chunks between them, a row in three chunks.  Self-zeroing on: every output row must come back defined."""
+    row = torch.tensor([0, 0, 2, 2, 2, 3, 6, 6, 9, 9])
+    ptr = torch.tensor([0, 0, 2, 2, 5, 6, 9, 9, 9, 12, 12])
+    n_rows, n_cols, E, d = 12, 7, 12, 64
+    idx = torch.tensor([1, 3, 0, 6, 6, 2, 5, 4, 1, 0, 3, 3])
+    eid = torch.randperm(E, generator=torch.Generator().manual_seed(3))
+    w = torch.rand(E, generator=torch.Generator().manual_seed(4))
+    X = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(5))
+    want = oracle.vector_spmm_forward(row, ptr, eid, idx, w, torch.cat([X, torch.zeros(n_rows - n_cols, d)]))[:n_rows]
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    _lib.tune("spmm_selfzero_min_mb", 0); _lib.tune("spmm_flat_cpg", fcpg); _lib.tune("spmm_flat_max_mean", 100)
+    _lib.tune("spmm_flat_min_chunks", 0)
+    _lib.tune("dense_blocks", 0)
+    try:
+        L = _lib.lib()
+        rd, pd, ed, idd, wd, Xd = (t.to(dev) for t in (row, ptr, eid, idx, w, X))
+        y = torch.full((n_rows, d), float("nan"), device=dev)
+        with _lib.device_guard(dev):
+            plan = _lib.get_plan(rd, pd, ed, idd, n_cols)
+            _lib.profile_enable(True)
+            _lib.check(L.graphop_vector_spmm_forward(_lib.dtype_code(Xd), _lib.ptr(rd), _lib.ptr(pd), _lib.ptr(ed), _lib.ptr(idd),
+                                                     _lib.ptr(wd), _lib.ptr(Xd), _lib.ptr(y), row.numel(), E, n_cols, n_rows, 1, d,
+                                                     plan.handle, _lib.stream_of(Xd)))
+            torch.cuda.synchronize()
+            prof = _lib.profile_read()
+        assert prof["spmm_fwd"]["kernel"] == "k_spmm_flat_f32", prof
+        assert not torch.isnan(y).any()
+        close(y, want)
     finally:
         _lib.profile_enable(False); _lib.tune_reset(); _lib.clear_plan_cache()

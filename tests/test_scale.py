@@ -276,7 +276,16 @@ def test_papers100m_shard_properties(dev):
     sh = ShardedAttention.synthetic(n_per_rank, e_per_rank, 8, 0, dev, alpha=0.5, seed=0, timing_only=True, cut=0.1)
     assert sh.n_halo > 0 and sh.graph.n_dst == sh.n_own + sh.n_halo
     assert int(sh.halo_ids.min()) >= n_per_rank                     # rank 0: every halo node lives on another rank
-    _shard_property_battery(dev, sh, 128)
+    _lib.profile_enable(True)
+    try:
+        _shard_property_battery(dev, sh, 128)
+        prof = _lib.profile_read()
+    finally:
+        _lib.profile_enable(False)
+    # the extended column side (29 M columns, half of them with one or two slots) runs the slot-walking chunk driver,
+    # the row side (13 slots per chunk) the per-chunk loop
+    assert prof["spmm_bwd_dx"]["kernel"] == "k_spmm_flat_f32" and prof["sddmm_bwd_dB"]["kernel"] == "k_spmm_flat_f32", prof
+    assert prof["sddmm_bwd_dA"]["kernel"] == "k_spmm_f32", prof
 
 
 def test_rmat25_shard_properties(dev):
