@@ -33,13 +33,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The hosts of this pool only support dmabuf IPC: with the legacy IPC mode RCCL's (and torch's) cross-process buffer
+# registration fails with `hipIpcGetMemHandle: invalid argument`.  The variable is read when the HSA runtime comes up,
+# i.e. at the first GPU call of the process -- so it is set HERE, before torch is imported, not next to
+# init_process_group (round 4 set it after torch.cuda.set_device had initialised the runtime: a no-op where it sat).
+# The image exports it already; setdefault keeps an explicit choice of the caller.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
 HBM_COPY_GBS = 6290.0   # measured device copy rate (MI355X_MICROARCH.md, chip level): informative only
-# random whole-row gathers of a table far beyond the Infinity Cache, each row fetched once
-# (MI355X_MICROARCH.md, "Indexed rows": 5.5-5.8 TB/s for 1-2 KB rows)
-HBM_RANDOM_ROW_GBS = 5700.0
+# whole-row gathers of a table far beyond the Infinity Cache, each row fetched once: the guide's HBM row of
+# "Indexed rows: gather into LDS" (MI355X_MICROARCH.md: 6.0-6.1 TB/s chip-wide; this repo's own random-row microbenchmark,
+# profiles/r4_tlb_reach.txt, reads 5.9-6.0 from 8-64 GB tables).  The upper figure, so that a fraction of it stays <= 1
+# (round 4 priced against 5.7 and printed 0.97-1.0 for the products shape)
+HBM_RANDOM_ROW_GBS = 6100.0
 # random 256-B row gathers by 16-lane groups from an L2-RESIDENT table, ids in registers, nothing else in the
 # loop (tools/microbench/l2_gather.hip, profiles/r1_l2_resident_sweep.txt; 28.5 TB/s with all XCDs walking the
 # windows in step, tools/microbench/cu_walk.hip, profiles/r2_cu_walk_microbench.txt): what a gather pass of a
@@ -150,6 +159,10 @@ def main():
     ap.add_argument("--d", "--dim", dest="d", type=int, default=0, help="per-head feature dim (0 = the workload's default)")
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--alpha", type=float, default=0.5, help="Chung-Lu power-law exponent (0 = uniform)")
+    ap.add_argument("--labeling", default="shuffled", choices=["shuffled", "degree", "clustered"],
+                    help="how node ids relate to the structure of the Chung-Lu graphs (graphs.chung_lu_graph): hubs spread "
+                         "over the ids | ids sorted by degree | stochastic-block communities of 1024 consecutive ids "
+                         "(p_in 0.9; generalises the reference fixture wrapper.py:84-112)")
     ap.add_argument("--values", default="uniform", help="uniform: U[0,1) like the harness | normal: N(0,1)/sqrt(d)")
     ap.add_argument("--cut", type=float, default=-1.0,
                     help="sharded graphs: fraction of a rank's edges whose destination is drawn from the GLOBAL "
@@ -193,21 +206,23 @@ def main():
     from custom_op_benchmark_amd import _lib, functions, graphs
     _lib.lib()  # fail loudly now if the extension is missing
 
+    import datetime
     import torch.distributed as dist
+    # a rank that dies during setup fails the run in two minutes (the other ranks' first collective times out), not at
+    # the driver's limit; GRAPHOP_DIST_TIMEOUT_S for slower hosts
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("GRAPHOP_DIST_TIMEOUT_S", "120")))
     if args.rccl_self:
         if world > 1 or args.emulate_world > 1:
             raise SystemExit("--rccl-self is the one-rank rehearsal of the RCCL path (no torchrun, no --emulate-world)")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
+        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev, timeout=pg_timeout)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("GRAPHOP_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a GPU
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
         if dist.get_backend() != backend:
@@ -262,7 +277,10 @@ def main():
         gdesc = "R-MAT(0.57,0.19,0.19,0.05) scale 22 (one eighth of scale 25)"
         del src, dst
     else:
-        g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev)
+        g = graphs.chung_lu_graph(N, E, alpha=args.alpha, seed=args.seed, chunk_size=args.chunk_size, device=dev,
+                                  labeling=args.labeling)
+        if args.labeling != "shuffled":
+            gdesc += ", node labeling: %s" % args.labeling
     n_rows, n_cols = g.n_src, g.n_dst
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1 + rank)
     shp = (lambda n: (n, d) if h == 1 else (n, h, d))
@@ -368,6 +386,29 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_edges * args.steps / elapsed
 
+    # sharded lines: what the exchanges cost the step = this step - the same step with every exchange a no-op (nothing
+    # is packed, sent, awaited or added; values involving halo rows are garbage: timing only), measured the same way
+    # (barrier + synchronize on both sides, max over ranks) right behind the timed region
+    exposed_ms = noop_ms = None
+    if runner is not None:
+        runner.noop_exchange = True
+        for _ in range(2):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        noop_el = time.perf_counter() - t0
+        runner.noop_exchange = False
+        if world > 1:
+            tt = torch.tensor([noop_el], device=cdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            noop_el = float(tt.item())
+        noop_ms = 1e3 * noop_el / args.steps
+        exposed_ms = ms_per_step - noop_ms
+        step()      # (halo rows valid again for what follows)
+
     # ---- the same step through the fused op (extra op: one autograd node, no E-sized intermediates) ----
     fused = None
     if runner is None and world == 1 and not args.no_fused and not args.hip_graph:
@@ -416,7 +457,7 @@ def main():
     # eid altogether, so an algorithmic fraction can exceed what the memory system delivered (softmax: 1.89 GB
     # algorithmic against 1.00 GB moved)
     sha = kernels_sha()
-    moved_by_kernel, moved_note = {}, "no profiles/pmc_traffic.json for this workload"
+    moved_by_kernel, moved_by_tag, moved_note = {}, {}, "no profiles/pmc_traffic.json for this workload"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -428,23 +469,43 @@ def main():
                               % (tj.get("kernels_sha"), sha))
             else:
                 moved_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items()}
+                # per pass tag where the counter passes could tell the launches of one instantiation apart (ADVICE r4:
+                # the row- and column-major launches of k_spmm_walk_f32 move different bytes)
+                moved_by_tag = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("passes", {}).items()}
                 moved_note = ("NOT measured in this run: rocprofv3 --pmc passes of this command on the same kernel sources "
-                              "(kernels_sha %s), profiles/pmc_traffic.json; per kernel family (row- and column-major "
-                              "launches of one instantiation are averaged); %s" % (sha, tj.get("note", "")))
+                              "(kernels_sha %s), profiles/pmc_traffic.json; per pass tag (launch order inside a step) where the "
+                              "file has it, else not quoted per pass; %s" % (sha, tj.get("note", "")))
         except (ValueError, KeyError):
             moved_note = "profiles/pmc_traffic.json unreadable"
     passes = {}
     kern = {}
+    if "sddmm_fwd_part" in prof and "sddmm_fwd" not in prof:
+        # sharded step: the SDDMM forward runs as an own-column and a halo-column launch over ONE score array (dist.py)
+        pp = prof.pop("sddmm_fwd_part")
+        prof["sddmm_fwd"] = dict(pp, mean_ms=pp["total_ms"] / nprof, launches_per_step=pp["calls"] // nprof)
+    # bytes of the survey's figure that the plan provably never moves: with eid == arange (row-major plans) the softmax
+    # kernels read NO edge ids at all (the int64 eid stream of E x 8 B is elided, not mirrored).  A per-pass fraction is
+    # quoted on the bytes that remain, so it cannot exceed what the memory system delivered; alg_GB stays the survey's.
+    try:
+        eid_identity = bool(_lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r).info.eid_identity)
+    except Exception:
+        eid_identity = False
     for tag in PASS_TAGS:
         if tag not in prof:
             continue
         ms = prof[tag]["mean_ms"]
         kname = prof[tag]["kernel"] or "?"
-        moved = moved_by_kernel.get(kname)
+        moved = moved_by_tag.get(tag)
+        elided = 8 * g.n_edges if (tag.startswith("softmax") and eid_identity) else 0
+        frac_bytes = pb[tag] - elided
         passes[tag] = {"ms": round(ms, 4), "kernel": kname, "alg_GB": round(pb[tag] / 1e9, 4),
-                       "alg_GBps": round(pb[tag] / 1e6 / ms, 1), "frac": round(pb[tag] / 1e6 / ms / HBM_PEAK_GBS, 4),
+                       "alg_GBps": round(pb[tag] / 1e6 / ms, 1),
+                       "elided_GB": round(elided / 1e9, 4),
+                       "frac": round(frac_bytes / 1e6 / ms / HBM_PEAK_GBS, 4),
                        "moved_GB": round(moved / 1e9, 4) if moved else None,
                        "moved_frac": round(moved / 1e6 / ms / HBM_PEAK_GBS, 4) if moved else None}
+        if "launches_per_step" in prof[tag]:
+            passes[tag]["launches_per_step"] = prof[tag]["launches_per_step"]
         fam = "k_spmm_*" if kname.startswith("k_spmm") else ("k_sddmm_*" if kname.startswith("k_sddmm") else kname)
         k = kern.setdefault(fam, {"ms": 0.0, "bytes": 0.0, "launches": 0, "names": set()})
         k["ms"] += ms; k["bytes"] += pb[tag]; k["launches"] += 1; k["names"].add(kname)
@@ -468,19 +529,38 @@ def main():
                          "frac_at_median_step": round(alg_step / 1e6 / statistics.median(step_ms) / HBM_PEAK_GBS, 4),
                          "kernel_ms_sum": round(sum(p["ms"] for p in passes.values()) +
                                                 sum(o["ms_per_step"] for o in other.values()), 3)},
-                "passes": passes, "passes_note": "frac = algorithmic bytes (API dtypes) / time / 8 TB/s; moved_GB / moved_frac = "
-                                                 "fabric-side bytes of the kernel family from the hardware counters: " + moved_note,
+                "passes": passes, "passes_note": "frac = (algorithmic bytes (API dtypes) - elided_GB) / time / 8 TB/s, elided_GB = the "
+                                                 "int64 eid stream a softmax pass over an identity-eid plan never reads; moved_GB / "
+                                                 "moved_frac = fabric-side bytes of that pass from the hardware counters: " + moved_note,
                 "other_launches": other}
     # tables far beyond the Infinity Cache with rows too short for column windows (products-shape): every
     # gathered edge is an HBM random-row read; what is physically reachable is that rate, not 8 TB/s of
     # algorithmic bytes -- a labelled secondary figure
     table_bytes = max(n_rows, n_cols) * h * d * 4
-    if table_bytes > (512 << 20) and passes:
+    # the secondary gather figures below price one neighbour row per edge and pass: they describe the GATHER drivers
+    # (chunk / window / walk kernels).  The block-dense MFMA drivers read every node row of a block ONCE per pass, so a
+    # "ceiling" built from per-edge gathers is not a bound for them (round 4 printed frac 1.78 there): not emitted.
+    gather_drivers = bool(passes) and not any("block" in (passes[t]["kernel"] or "") for t in GATHER_TAGS if t in passes)
+    # hard bound that needs no microbenchmark: every gathered edge moves its F x 4-byte row through a CU's vector L1,
+    # 64 B per clock and CU (MI355X_MICROARCH.md, memory hierarchy), whatever the L2 does; + the softmax passes at 8 TB/s
+    if gather_drivers:
+        props = torch.cuda.get_device_properties(dev)
+        clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+        cus = int(props.multi_processor_count)
+        l1_rate = 64.0 * cus * clk_hz                       # B/s: 39.3 TB/s at 256 CUs x 2.4 GHz
+        soft_b = sum(pb[t] for t in PASS_TAGS if t.startswith("softmax")) - (16 * g.n_edges if eid_identity else 0)
+        l1_ms = 6.0 * g.n_edges * h * d * 4 / l1_rate * 1e3 + soft_b / 1e6 / HBM_PEAK_GBS
+        roofline["l1_bound_ms"] = round(l1_ms, 3)
+        roofline["l1_bound"] = {"what": "hard lower bound of the 8-function step on this device: 6 gather passes x E x F x 4 B through "
+                                        "the CUs' vector L1s at 64 B/clk/CU + the two softmax passes at 8 TB/s",
+                                "cus": cus, "clock_MHz": round(clk_hz / 1e6, 1), "l1_rate_TBps": round(l1_rate / 1e12, 2),
+                                "frac_of_bound": round(l1_ms / ms_per_step, 4)}
+    if table_bytes > (512 << 20) and gather_drivers:
         gbytes = 6.0 * g.n_edges * h * d * 4
         gms = sum(passes[t]["ms"] for t in GATHER_TAGS if t in passes)
         roofline["gather_roofline"] = {
             "what": "secondary: 6 gather passes x E x F x 4 B of neighbour rows at the measured HBM random-row rate "
-                    "(MI355X_MICROARCH.md, Indexed rows: 5.5-5.8 TB/s); the tables (%.1f GB each) are beyond the Infinity Cache"
+                    "(MI355X_MICROARCH.md, Indexed rows, HBM: 6.0-6.1 TB/s); the tables (%.1f GB each) are beyond the Infinity Cache"
                     % (table_bytes / 1e9),
             "gather_bytes": int(gbytes), "peak_GBps": HBM_RANDOM_ROW_GBS, "achieved_GBps": round(gbytes / 1e6 / gms, 1),
             "frac": round(gbytes / 1e6 / gms / HBM_RANDOM_ROW_GBS, 4),
@@ -488,7 +568,7 @@ def main():
     # tables that fit the Infinity Cache (Reddit-shape: 59.6 MB): the gathers can be L2 hits when the passes
     # are organised in column windows; the reachable ceiling of the 8-function step is then six gather
     # passes at the L2-resident gather rate plus the two softmax passes at the HBM roofline
-    if table_bytes <= (512 << 20) and passes:
+    if table_bytes <= (512 << 20) and gather_drivers:
         gbytes = 6.0 * g.n_edges * h * d * 4
         soft_bytes = sum(pb[t] for t in PASS_TAGS if t.startswith("softmax"))
         ceil_ms = gbytes / 1e6 / L2_GATHER_GBS + soft_bytes / 1e6 / HBM_PEAK_GBS
@@ -548,6 +628,10 @@ def main():
             step()
         torch.cuda.synchronize()
         cfg["halo"]["exchange_ms"] = {k: round(1e3 * statistics.median(v), 3) for k, v in runner.timers.items()}
+        # bytes one rank receives + sends in that exchange over its wall time (halo_KV carries both tables)
+        per_x = cfg["halo"]["bytes_per_exchange_in"] + cfg["halo"]["bytes_per_exchange_out"]
+        cfg["halo"]["exchange_GBps_in_plus_out"] = {k: round((2 if k == "halo_KV" else 1) * per_x / 1e6 / max(1e-6, v), 1)
+                                                    for k, v in cfg["halo"]["exchange_ms"].items()}
         # --emulate-world: the "exchanges" are local copies of the right sizes on this GPU, NOT link times
         cfg["halo"]["exchange_ms_is_local_copy"] = bool(runner.emulate)
         if args.rccl_self:
@@ -577,6 +661,14 @@ def main():
         "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }
+    if exposed_ms is not None:
+        out["exposed_exchange_ms"] = round(exposed_ms, 4)
+        out["step_without_exchanges_ms"] = round(noop_ms, 4)
+        out["exposed_exchange_note"] = ("ms_per_step minus the same step with every halo exchange (pack, collective, wait, add-home) "
+                                        "a no-op, timed the same way right behind the timed region; all four exchanges run "
+                                        "under compute (dist.py), so this is what the overlap does NOT hide"
+                                        + ("; NB exchanges here are local copies on this GPU, not link transfers"
+                                           if (runner is not None and runner.emulate) else ""))
     if single_ref_ms is not None:
         out["single_gpu_reference_ms"] = round(single_ref_ms, 4)
         out["single_gpu_reference"] = ("rank %d's shard in this process with every halo exchange replaced by a local copy of "

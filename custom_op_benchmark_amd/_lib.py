@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHOP_LIB") or os.path.join(_HERE, "libgraphop_hip.so")   # override: A/B builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, F64 = 0, 1
 _c64 = ctypes.c_int64
@@ -29,7 +29,8 @@ class PlanInfo(ctypes.Structure):
                 ("indptr_monotone", ctypes.c_int32), ("eid_identity", ctypes.c_int32),
                 ("full_coverage", ctypes.c_int32), ("row_owned", ctypes.c_int32),
                 ("has_idx32", ctypes.c_int32), ("dense_fill_pct", ctypes.c_int32),
-                ("sorted_in_rows", ctypes.c_int32), ("n_dense_blocks", _c64)]
+                ("sorted_in_rows", ctypes.c_int32), ("n_dense_blocks", _c64), ("max_row_gap", _c64),
+                ("n_geometry_fallbacks", _c64)]
 
 
 class SweepInfo(ctypes.Structure):
@@ -69,6 +70,7 @@ _SIGNATURES = {
     "graphop_plan_sweep_dealt": [_P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)],
     "graphop_plan_sweep_build_dealt": [_P, ctypes.POINTER(SweepInfo), ctypes.c_int32, ctypes.c_int32, _P],
     "graphop_maskedmm_csr_forward": [ctypes.c_int] + [_P] * 7 + [_c64] * 6 + [_P, _P],
+    "graphop_maskedmm_csr_forward_partial": [ctypes.c_int] + [_P] * 7 + [_c64] * 7 + [_P],
     "graphop_maskedmm_csr_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_sparse_softmax_forward": [ctypes.c_int] + [_P] * 5 + [_c64] * 3 + [_P, _c64, _P, _P],
     "graphop_sparse_softmax_backward": [ctypes.c_int] + [_P] * 6 + [_c64] * 3 + [_P, _c64, _P, _P],
@@ -175,9 +177,11 @@ def check(rc):
 
 
 def check_errors(sync=True):
-    """Raise if a kernel of an earlier launch reported a failure through the device error word (a walk kernel whose
-    hand-over spin expired: include/graphop_hip.h, graphop_check_device_errors).  sync=True waits for the device
-    first, so every launch made so far is covered."""
+    """Raise if a kernel of an earlier launch reported a failure through the device error record (a walk kernel whose
+    hand-over spin expired: include/graphop_hip.h, graphop_check_device_errors) and CLEAR the record -- it is sticky
+    (ABI 7): until this call acknowledges it, every op entry point fails with the same message.  sync=True waits for
+    the device first, so every launch made so far is covered; sync=False only looks (one host-memory load: the steps
+    call it on their way out, so an abort in the LAST launch of a step is reported at the latest by the next step)."""
     if sync and torch.cuda.is_available():
         torch.cuda.synchronize()
     check(lib().graphop_check_device_errors())
@@ -313,6 +317,11 @@ class Plan:
         with torch.cuda.device(self.tensors[1].device):
             check(lib().graphop_plan_prepare(self.handle, dtype, int(n_table_rows), int(h), int(d),
                                              int(fused), stream_of(self.tensors[1])))
+
+    def refresh_info(self):
+        """Re-read the info record (n_geometry_fallbacks is a live count: include/graphop_hip.h)."""
+        check(lib().graphop_plan_info(self.handle, ctypes.byref(self.info)))
+        return self.info
 
     def __repr__(self):
         i = self.info

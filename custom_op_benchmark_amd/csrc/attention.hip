@@ -254,7 +254,7 @@ int graphop_attention_forward(int dtype, const int64_t* row, const int64_t* indp
                               int64_t n_k, int64_t h, int64_t d, void* workspace,
                               int64_t workspace_bytes, const graphop_plan_t* plan, void* stream) {
   const char* fn = "attention_forward";
-  GO_TRY(check_async_error());
+  GO_TRY(check_async_error(false));
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
   GO_CHECK_ARG(n_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 && h >= 1 && d >= 0,
                "%s: negative size", fn);
@@ -310,7 +310,7 @@ int graphop_attention_backward(int dtype, const int64_t* row, const int64_t* ind
                                int64_t workspace_bytes, const graphop_plan_t* plan_r,
                                const graphop_plan_t* plan_c, void* stream) {
   const char* fn = "attention_backward";
-  GO_TRY(check_async_error());
+  GO_TRY(check_async_error(false));
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: bad dtype", fn);
   GO_CHECK_ARG(n_row_chunks >= 0 && n_col_chunks >= 0 && n_edges >= 0 && n_q >= 0 && n_k >= 0 &&
                h >= 1 && d >= 0, "%s: negative size", fn);

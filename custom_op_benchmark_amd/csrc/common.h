@@ -62,7 +62,8 @@ int check_not_capturing(hipStream_t st, const char* what);
 // Device-side failures (kernels_walk.h: walk_fail) are reported through one host-mapped word: kernels store a code,
 // the host looks at it at the start of every entry point and in graphop_check_device_errors (graphop_hip.hip).
 int* device_error_word(bool create);   // device-visible pointer (nullptr when there is none yet and !create)
-int check_async_error();               // GRAPHOP_OK, or GRAPHOP_ERR_HIP with the message set (the word is cleared)
+int check_async_error(bool clear = false);   // GRAPHOP_OK, or GRAPHOP_ERR_HIP with the message set; the record is sticky unless clear
+int walk_launch_id(const char* tag);     // sequence number of the walk launch about to be made under this pass tag
 
 // ---- plan (host view) ---------------------------------------------------------------------------
 struct PlanStats {  // device-resident while the analysis kernels run, then copied back
@@ -72,6 +73,7 @@ struct PlanStats {  // device-resident while the analysis kernels run, then copi
   i64 bad_eid;           // #k with eid[k] outside [0, E)
   i64 bad_index;         // #k with indices[k] outside [0, bound)
   i64 max_row;
+  i64 max_gap;           // most consecutive row ids without a chunk in front of a chunk's row (sorted rows: the longest run of edge-less rows)
   i64 max_index;
   i64 max_seg_len;
   i64 n_segments;
@@ -360,12 +362,14 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 // Float max through integer atomics (no CAS loop): non-negative floats order like ints,
 // negative floats order inversely as unsigned.
 __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  v += 0.f;   // -0.0f -> +0.0f: as an int, -0.0f is INT_MIN and would lose against every stored value
   if (v >= 0.f)
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else
     atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_max_float(double* addr, double v) {
+  v += 0.0;
   if (v >= 0.0)
     atomicMax(reinterpret_cast<long long*>(addr), __double_as_longlong(v));
   else

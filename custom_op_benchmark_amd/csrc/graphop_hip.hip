@@ -157,10 +157,15 @@ hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
   return hipGetLastError();
 }
 
-// ---- device-side error word ----------------------------------------------------------------------------
+// ---- device-side error record ---------------------------------------------------------------------------
+// Host-mapped words written by kernels: [0] = code, [1] = sequence number of the walk launch that failed.  STICKY
+// (ABI 7): entry points fail while [0] is set; only graphop_check_device_errors (clear = true) resets it.
 static int* g_err_host = nullptr;   // hipHostMalloc'ed (mapped, coherent): written by kernels, read here
 static int* g_err_dev = nullptr;
 static std::mutex g_err_mu;
+struct WalkLaunchRec { const char* tag; int device; unsigned seq; };
+static WalkLaunchRec g_walk_ring[256];   // the last 256 walk launches: sequence number -> pass tag, device
+static unsigned g_walk_seq = 0;
 int* device_error_word(bool create) {
   std::lock_guard<std::mutex> lk(g_err_mu);
   if (!g_err_host && create) {
@@ -175,19 +180,40 @@ int* device_error_word(bool create) {
   }
   return g_err_dev;
 }
-int check_async_error() {
-  int code = 0;
+// sequence number of the walk launch about to be made under pass tag `tag` (kept so that a failure can be named)
+int walk_launch_id(const char* tag) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  const unsigned seq = ++g_walk_seq;
+  g_walk_ring[seq & 255] = WalkLaunchRec{tag, dev, seq};
+  return (int)seq;
+}
+int check_async_error(bool clear) {
+  int code = 0, seq = 0;
+  WalkLaunchRec rec{nullptr, -1, 0};
   {
     std::lock_guard<std::mutex> lk(g_err_mu);
     if (!g_err_host) return GRAPHOP_OK;
-    code = __atomic_exchange_n(g_err_host, 0, __ATOMIC_ACQ_REL);
+    code = __atomic_load_n(g_err_host, __ATOMIC_ACQUIRE);
+    if (code == 0) return GRAPHOP_OK;
+    seq = __atomic_load_n(g_err_host + 1, __ATOMIC_ACQUIRE);
+    if (g_walk_ring[(unsigned)seq & 255].seq == (unsigned)seq) rec = g_walk_ring[(unsigned)seq & 255];
+    if (clear) {
+      __atomic_store_n(g_err_host + 1, 0, __ATOMIC_RELEASE);
+      __atomic_store_n(g_err_host, 0, __ATOMIC_RELEASE);
+    }
   }
-  if (code == 0) return GRAPHOP_OK;
   const char* what = code == kWalkErrQuad ? "a (step, quad) unit waited for its quad's previous step"
                    : code == kWalkErrRing ? "a worker wave waited for a ring chunk of its feeder wave"
                    : "unknown code";
-  set_error("a walk kernel (k_spmm_walk_* / k_attn_fwd_walk_f32) of an earlier launch aborted: %s until its spin bound expired (device "
-            "error code %d); the outputs of that launch are invalid", what, code);
+  char where[96];
+  if (rec.tag) snprintf(where, sizeof(where), "pass '%s' on device %d, walk launch #%d", rec.tag, rec.device, seq);
+  else snprintf(where, sizeof(where), "walk launch #%d", seq);
+  set_error("a walk kernel (k_spmm_walk_* / k_attn_fwd_walk_f32) of an earlier launch aborted (%s): %s until its spin bound "
+            "expired (device error code %d); the outputs of that launch and of every launch that consumed them are invalid%s",
+            where, what, code,
+            clear ? "" : " -- sticky: graphop_check_device_errors() acknowledges and clears it");
   return GRAPHOP_ERR_HIP;
 }
 
@@ -466,6 +492,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t s
     out->view.sync = (t.walk_drift > 0 && !dry_run) ? plan_take_walk_sync(const_cast<graphop_plan*>(plan), wk) : nullptr;
     out->view.dbg = nullptr;
     out->view.err = device_error_word(false);   // (created with the plan's first walk layout, never during a capture)
+    out->view.launch_id = 0;                     // (set by the launcher: walk_launch_id(tag))
     out->view.fault = t.walk_fault;
     out->view.stream_weights = pi.eid_identity ? 1 : 0;
     out->blocks = (unsigned)blocks;
@@ -505,6 +532,7 @@ int try_spmm_walk(const char* tag, int dtype, const graphop_plan* plan, i64 n_ta
     if (use != 1) return use;
     WalkDebug dbg;
     dbg.arm(&wl, tag, st, kWalkWorkers / kWave);
+    wl.view.launch_id = walk_launch_id(tag);
     ProfScope prof(tag, st, dtype == GRAPHOP_F64 ? "k_spmm_walk_f64" : "k_spmm_walk_f32");
     auto launch = [&](auto kfn, size_t lds_bytes, auto... args) {
       allow_full_lds((const void*)kfn);
@@ -592,6 +620,7 @@ int attn_fwd_walk(const graphop_plan* plan, i64 n_q, i64 n_k, i64 h, i64 d, int 
   {
     WalkDebug dbg;
     dbg.arm(&wl, "attn_fwd", st, kWalkWorkers / kWave);
+    wl.view.launch_id = walk_launch_id("attn_fwd");
     ProfScope prof("attn_fwd", st, "k_attn_fwd_walk_f32");
     allow_full_lds((const void*)k_attn_fwd_walk_f32<L>);
     const size_t lds_bytes = (size_t)(kWalkWorkers / L) * attn_walk_group_bytes<L>(KR);
@@ -789,6 +818,9 @@ inline bool spmm_selfzero(int dtype, const i64* row, const i64* indptr, const i6
   if (plan->info.max_row >= n_out_rows || n_out_rows >= 0x7fffffffLL) return false;
   if ((double)n_out_rows * (double)(h * d) * 4.0 < (double)t.spmm_selfzero_min_mb * 1048576.0) return false;
   if (spmm_block_applies(dtype, plan, n_table_rows, X, out, h, d)) return false;
+  // rows without edges between two chunk rows are zero-stored by ONE lane group per gap, serially (the tail behind the
+  // last row is the host's: launch_spmm): a gap of more than 4 MB of rows is the device-wide fill's job after all
+  if ((double)plan->info.max_row_gap * (double)(h * d) * 4.0 > 4.0 * 1048576.0) return false;
   int use = 0;
   GO_DISPATCH_LNV((int)(h * d), {
     if constexpr (NV == 1 && L >= 16) {
@@ -891,6 +923,13 @@ int launch_spmm(const char* tag, int dtype, const i64* row, const i64* indptr, c
       const bool flat = spmm_flat(C, E, h, d);
       const int cpg = cpg_for(C, flat ? tuning().spmm_flat_cpg : tuning().spmm_cpg, (int)(h * d));
       const int F = (int)(h * d), d4 = (int)(d / 4);
+      // the rows behind the last chunk row (trailing nodes without edges) are zeroed from here, device-wide: left to the
+      // kernel they are one lane group's serial stores (an output with a long empty tail: GBs through 16-64 lanes)
+      if (plan && plan->info.max_row + 1 < selfzero_rows) {
+        const i64 covered = plan->info.max_row + 1;
+        GO_HIP(zero_async((char*)out + sizeof(float) * (size_t)(covered * F), sizeof(float) * (size_t)((selfzero_rows - covered) * F), st));
+        selfzero_rows = covered;
+      }
       ProfScope prof(tag, st, flat ? "k_spmm_flat_f32" : "k_spmm_f32");
       GO_DISPATCH_LNV(F, {
         const i64 groups = ceil_div(C, cpg);
@@ -1139,7 +1178,7 @@ int softmax_backward_t(const i64* row, const i64* indptr, const i64* eid, const 
 }
 
 inline int check_common(const char* fn, int dtype, i64 C, i64 E, i64 h, i64 d) {
-  GO_TRY(check_async_error());   // a kernel of an earlier launch reported a failure
+  GO_TRY(check_async_error(false));   // a kernel of an earlier launch reported a failure: sticky until acknowledged
   GO_CHECK_ARG(dtype == GRAPHOP_F32 || dtype == GRAPHOP_F64, "%s: dtype must be GRAPHOP_F32 or "
                "GRAPHOP_F64", fn);
   GO_CHECK_ARG(C >= 0 && E >= 0 && h >= 1 && d >= 0, "%s: negative size (n_chunks=%lld n_edges=%lld "
@@ -1238,7 +1277,7 @@ int64_t graphop_memory_bytes(void) {
   return (int64_t)g_bytes;
 }
 
-int graphop_check_device_errors(void) { return check_async_error(); }
+int graphop_check_device_errors(void) { return check_async_error(true); }
 
 int graphop_tune_reset(void) {
   tuning_mut() = Tuning();   // the defaults (environment overrides included), as at library load
@@ -1446,6 +1485,7 @@ int graphop_plan_import(const int64_t* row, const int64_t* indptr, const int64_t
   GO_CHECK_ARG(p != nullptr, "plan_import: out of host memory");
   p->row = row; p->indptr = indptr; p->eid = eid; p->indices = indices;
   p->info = *info;
+  p->info.n_geometry_fallbacks = 0;   // (a live count of this plan object, not part of the persisted state)
   (void)hipGetDevice(&p->device);
   plan_init_sweeps(p);
   int rc = plan_import_arrays(p, (const i64*)seg_chunk, idx32, eid32, long_segs, n_long, blk_seg, seg_e0,
@@ -1526,6 +1566,24 @@ int graphop_maskedmm_csr_forward(int dtype, const int64_t* row, const int64_t* i
   }
   return launch_sddmm<false>("sddmm_fwd", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
                              (const i64*)indices, A, B, y, n_chunks, n_edges, n_b, h, d, plan, st);
+}
+
+// SDDMM over a subset of the slots into a shared result array: no zero fill, eid indexes y (n_y entries).
+int graphop_maskedmm_csr_forward_partial(int dtype, const int64_t* row, const int64_t* indptr,
+                                         const int64_t* eid, const int64_t* indices, const void* A,
+                                         const void* B, void* y, int64_t n_chunks, int64_t n_slots,
+                                         int64_t n_y, int64_t n_a, int64_t n_b, int64_t h, int64_t d,
+                                         void* stream) {
+  const char* fn = "maskedmm_csr_forward_partial";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_slots, h, d));
+  GO_CHECK_ARG(n_y >= n_slots && n_a >= 0 && n_b >= 0, "%s: n_y (%lld) must be at least n_slots (%lld): eid[] names distinct "
+               "entries of y", fn, (long long)n_y, (long long)n_slots);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_slots * h == 0 || n_chunks == 0) return GRAPHOP_OK;
+  GO_PTR(fn, y); GO_PTR(fn, row); GO_PTR(fn, indptr); GO_PTR(fn, eid); GO_PTR(fn, indices); GO_PTR(fn, A); GO_PTR(fn, B);
+  // E bounds the 32-bit forms of the kernels' edge offsets: the result array's size, not the sub-graph's
+  return launch_sddmm<false>("sddmm_fwd_part", dtype, (const i64*)row, (const i64*)indptr, (const i64*)eid,
+                             (const i64*)indices, A, B, y, n_chunks, n_y, n_b, h, d, nullptr, st);
 }
 
 int graphop_maskedmm_csr_backward(int dtype, const int64_t* row, const int64_t* indptr_r,

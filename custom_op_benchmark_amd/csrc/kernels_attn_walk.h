@@ -289,8 +289,10 @@ __device__ __forceinline__ void attn_fwd_walk_body(const WalkView& s, const Attn
           const float sc = attn_exp(m_c - mx);
           const float p = pad ? 0.f : attn_exp(sv - mx);
           l_c = fmaf(l_c, sc, p);
-          o_c.x = fmaf(o_c.x, sc, p * x1[u].x); o_c.y = fmaf(o_c.y, sc, p * x1[u].y);
-          o_c.z = fmaf(o_c.z, sc, p * x1[u].z); o_c.w = fmaf(o_c.w, sc, p * x1[u].w);
+          // (a select, not 0 * V: a padding slot gathers SOME valid row, and a non-finite value there must not reach this row)
+          const float4 xv = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : x1[u];
+          o_c.x = fmaf(o_c.x, sc, p * xv.x); o_c.y = fmaf(o_c.y, sc, p * xv.y);
+          o_c.z = fmaf(o_c.z, sc, p * xv.z); o_c.w = fmaf(o_c.w, sc, p * xv.w);
           m_c = mx;
         });
         mc = mn; off_c = off_n;
@@ -334,7 +336,7 @@ __device__ __forceinline__ void attn_fwd_walk_body(const WalkView& s, const Attn
     if ((threadIdx.x & (kWave - 1)) == 0) lds_st(quad_done + q, gstep + 1);
     pacer.signal_slot(q, gstep + 1);
   }
-  walk_report(s.err, &wg_abort);
+  walk_report(s.err, s.launch_id, &wg_abort);
   pacer.report(s.dbg, t_start);
 }
 

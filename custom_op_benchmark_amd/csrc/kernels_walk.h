@@ -39,7 +39,8 @@ struct WalkView {
   int xcd_slots;         // grid % xcd_slots == 0; workgroup b serves XCD slot b % xcd_slots
   int stream_weights;    // 1: the per-slot weights are read in storage order (identity eid): nontemporal loads
   long long* dbg;        // diagnostics (knob walk_debug): per wave {cycles in the kernel, cycles waiting in the pacer, waits, XCC id}
-  int* err;              // host-visible error word (host.h: device_error_word): a hand-over that timed out stores its code here
+  int* err;              // host-visible error record (host.h: device_error_word): a hand-over that timed out stores its code here
+  int launch_id;         // ... and this launch's sequence number next to it (graphop_hip.hip: walk_launch_id), so the host can name the pass
   int fault;             // fault injection (knob walk_fault, tests only): 1 = the feeders never deliver chunk 1 of lane group 0,
                          // 2 = quad 0 never reports step 0 finished
 };
@@ -68,10 +69,12 @@ __device__ __forceinline__ int walk_aborted(const int* wg_abort) {
 __device__ __forceinline__ void walk_fail(int* wg_abort, int code) {
   __hip_atomic_store(wg_abort, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void walk_report(int* err, const int* wg_abort) {
+__device__ __forceinline__ void walk_report(int* err, int launch_id, const int* wg_abort) {
   const int code = walk_aborted(wg_abort);
-  if (code != 0 && err != nullptr && (threadIdx.x & (kWave - 1)) == 0)
-    __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (code != 0 && err != nullptr && (threadIdx.x & (kWave - 1)) == 0) {
+    __hip_atomic_store(err + 1, launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 constexpr int kWalkIdMask = (1 << kWalkKShift) - 1;
@@ -592,7 +595,7 @@ __device__ __forceinline__ void spmm_walk_body(
     if ((threadIdx.x & (kWave - 1)) == 0 && !(s.fault == 2 && q == 0 && gstep == 0)) lds_st(quad_done + q, gstep + 1);
     pacer.signal_slot(q, gstep + 1);
   }
-  walk_report(s.err, &wg_abort);     // (the worker waves always get here: every spin of theirs polls the abort flag)
+  walk_report(s.err, s.launch_id, &wg_abort);     // (the worker waves always get here: every spin of theirs polls the abort flag)
   pacer.report(s.dbg, t_start);
 }
 

@@ -12,14 +12,26 @@ asks for it.  Design:
   n_own x (n_own + n_halo) chunked CSR and runs through the unchanged single-GPU operators.
 * Forward exchange: a variable-size all_to_all delivers the halo rows of K (and one more those of
   V) straight into the tail of preallocated extended tensors -- no packing, no concatenation.
-  Both are started together (async); the V rows are awaited only in front of the SpMM, the
-  returning dV rows travel under the softmax / SDDMM backward, and the returning dK rows under the
-  row-major half of the SDDMM backward (the op is called once per orientation): three of the four
-  exchanges overlap with compute.  The forward K exchange is exposed: hiding it needs the local
-  graph split into own-column and halo-column halves with outputs accumulated in place, which
-  the reference's operator surface (fresh zero-filled outputs per call) does not offer -- composed
-  from whole-output calls it costs more zero fills and adds than the ~4 % it would hide at the
-  papers100M-shape shard.
+  Both are started together (async).  ALL FOUR exchanges of a step now run under compute (round 5):
+  - K under the OWN-COLUMN half of the SDDMM forward.  Inside every row of the local CSR the own
+    columns come first, then the halo columns; the constructor cuts the row-major slots into an
+    own-column and a halo-column sub-graph -- two (row, indptr, eid, indices) sets whose `eid` name
+    positions of the ONE shared score array s.  Every edge score is written exactly once
+    (graphop_kernel.cu:45-52), so the two halves need no zero fill and no add
+    (graphop_maskedmm_csr_forward_partial, include/graphop_hip.h): the own half (~90 % of the
+    edges at cut = 0.1) is launched right after the K exchange is STARTED, wait_k.wait(), then the
+    halo half.  (Round 4 left this exchange exposed with the argument that halves cost "more zero
+    fills and adds than they hide" -- true of SpMM-type outputs, not of the SDDMM.)
+  - V under the SDDMM and the softmax, the returning dV rows under the softmax / SDDMM backward, the
+    returning dK rows under the row-major half of the SDDMM backward (the op is called once per
+    orientation).
+  `pack_kv`: K and V halo rows can travel as ONE grouped exchange (torch.distributed.
+  batch_isend_irecv: one RCCL group launch whose receives land directly in the two extended
+  tensors; 3 collectives per step instead of 4, one wait).  A group completes as a whole, so the
+  halo half of the SDDMM then waits for the V rows as well: worth it while the exchange is
+  latency-bound (small halos), not when it is link-bound (DESIGN.md section 6 prices both); the
+  default "auto" packs below PACK_KV_MAX_BYTES per exchange.  dK | dV cannot be packed: dV is ready one
+  column-major pass earlier than dK and travels under it.
   Backward exchange: the partial dK / dV rows computed for halo columns (a contiguous slice of the
   operators' outputs) travel back with the transposed split sizes and are added into the owners' rows.
   xGMI is point-to-point: all_to_all drives all 7 links of a GPU at once; no ring collective.
@@ -56,6 +68,24 @@ class _Done:
 
 
 _DONE = _Done()
+# pack_kv = "auto": K | V halo rows travel as one grouped exchange while both directions of one exchange stay below
+# this many bytes (latency-bound); above it K goes first on its own, because the halo half of the SDDMM waits for it
+PACK_KV_MAX_BYTES = 16 << 20
+
+
+class _Works:
+    """wait() on every work object of a grouped exchange (batch_isend_irecv returns one per op, or one per group)."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        # idempotent: K | V share one group handle, awaited once in front of each consumer (a second wait() on a
+        # finished gloo send / recv work never returns)
+        works, self.works = self.works, []
+        for w in works:
+            w.wait()
+        return True
 
 
 class LocalGroup:
@@ -134,7 +164,8 @@ def run_local_shards(world, fn, timeout=300.0):
 
 class ShardedAttention:
     def __init__(self, rank, world, bounds, src_global, dst_global, device, chunk_size=32, ops=None,
-                 group=None, timing_only=False, force_collectives=False, halo_mask=None):
+                 group=None, timing_only=False, force_collectives=False, halo_mask=None, split_forward=True,
+                 pack_kv="auto"):
         """src_global/dst_global: the edges whose source lies in this rank's range (any order).
         group: a torch.distributed process group (None = default), or a LocalGroup handle (all shards
         in this process, exchanges are device copies: exact results on one GPU).
@@ -158,6 +189,11 @@ class ShardedAttention:
         # SDDMM backward as two calls (column-major half, then row-major half) so that the dK halo
         # exchange runs under the dQ pass; costs one extra zero fill of a K_ext-sized tensor
         self.split_backward = True
+        # SDDMM forward as an own-column half (runs under the K exchange) and a halo-column half (after it)
+        self.split_forward = bool(split_forward) and os.environ.get("GRAPHOP_DIST_SPLIT_FORWARD", "1") != "0"
+        self.pack_kv = {"0": False, "1": True}.get(os.environ.get("GRAPHOP_DIST_PACK_KV", ""), pack_kv)   # True / False / "auto"
+        self.noop_exchange = False        # bench.py: exchanges do nothing at all (timing only: what a step costs without them)
+        self.collectives_last_step = 0
         self.device = torch.device(device)
         self.ops = ops
         lo, hi = bounds[rank], bounds[rank + 1]
@@ -194,6 +230,27 @@ class ShardedAttention:
         self.send_counts = send_counts
         self.serve_rows = serve                                # our rows, grouped by destination peer
         self._serve_groups = None                              # (ptr, rows, pos) of serve_rows, for the HIP add-home kernel
+        self.fwd_halves = self._cut_forward_halves(chunk_size) if (self.split_forward and self.n_halo > 0) else None
+
+    def _cut_forward_halves(self, chunk_size):
+        """Own-column and halo-column sub-graphs of the row-major local CSR.  A row's slots are sorted by local column
+        id, own columns (< n_own) first; each half is (row, indptr, slots, indices, eid_local): a chunked CSR over the
+        half's slots in their original order, `slots` = their positions in the full slot array (= the entries of the
+        shared score array they write: the `eid` of graphop_maskedmm_csr_forward_partial), `indices` = their extended
+        local column ids, `eid_local` = arange (for operator sets that only offer the reference surface)."""
+        from .part_csr import partition_csr
+        g = self.graph
+        own = g.indices_r < self.n_own
+        cum = torch.zeros(g.n_edges + 1, dtype=torch.int64, device=own.device)
+        torch.cumsum(own, 0, out=cum[1:])
+        ip_own = cum[g.indptr_r]
+        halves = []
+        for mask, ip in ((own, ip_own), (~own, g.indptr_r - ip_own)):
+            slots = torch.nonzero(mask).flatten()
+            row, ptr_ = partition_csr(ip.contiguous(), chunk_size)
+            halves.append(dict(row=row, ptr=ptr_, slots=slots, indices=g.indices_r[slots].contiguous(),
+                               eid_local=torch.arange(slots.numel(), dtype=torch.int64, device=slots.device)))
+        return halves
 
     # ---- collectives ---------------------------------------------------------------------------
     def _exchange_counts(self, counts):
@@ -228,6 +285,9 @@ class ShardedAttention:
         """Variable-size all-to-all (splits count rows).  Returns a handle whose wait() orders the
         current stream (RCCL) / the caller (gloo) after the exchange; already complete unless
         async_op was requested on a real process group."""
+        if self.noop_exchange:
+            return _DONE
+        self.collectives_last_step += 1
         if self.world == 1 and not self.force:
             out.copy_(inp)
             return _DONE
@@ -248,6 +308,54 @@ class ShardedAttention:
             return _DONE
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
         return work if async_op else _DONE
+
+    def _all_to_all_group(self, pairs, out_splits, in_splits, async_op=False):
+        """Several variable-size all-to-alls with the SAME split sizes as ONE grouped exchange: pairs = [(out, inp), ...].
+        On a real process group this is torch.distributed.batch_isend_irecv -- under RCCL one ncclGroupStart/End launch
+        whose receives land directly in the `out` tensors (which is also what all_to_all_single is made of); everywhere
+        else (no peers, emulation, LocalGroup, gloo staging of device tensors) one all-to-all per pair."""
+        if self.noop_exchange:
+            return _DONE
+        real = not ((self.world == 1 and not self.force) or self.emulate or self.local is not None)
+        if real and not (pairs[0][0].is_cuda and dist.get_backend(self.group) == "gloo"):
+            nccl = dist.get_backend(self.group) == "nccl"
+            ops, oo, io = [], 0, 0
+            for p in range(self.world):
+                for out, inp in pairs:               # per peer: K send, K recv, V send, V recv -- the same order on every rank
+                    src_seg, dst_seg = inp[io:io + in_splits[p]], out[oo:oo + out_splits[p]]
+                    if p == self.rank and not nccl:  # (gloo has no send-to-self; RCCL matches it inside the group)
+                        dst_seg.copy_(src_seg)
+                        continue
+                    if in_splits[p]:
+                        ops.append(dist.P2POp(dist.isend, src_seg, group=self.group, group_peer=p))
+                    if out_splits[p]:
+                        ops.append(dist.P2POp(dist.irecv, dst_seg, group=self.group, group_peer=p))
+                oo += out_splits[p]
+                io += in_splits[p]
+            self.collectives_last_step += 1
+            if not ops:
+                return _DONE
+            w = _Works(dist.batch_isend_irecv(ops))
+            if not async_op:
+                w.wait()
+                return _DONE
+            return w
+        return _Works([self._all_to_all(o, i, out_splits, in_splits, async_op) for o, i in pairs])
+
+    def _pack_kv_now(self, row_bytes):
+        if self.pack_kv == "auto":
+            return max(self.n_halo, int(self.serve_rows.numel())) * row_bytes <= PACK_KV_MAX_BYTES
+        return bool(self.pack_kv)
+
+    def gather_halos_grouped(self, pairs, async_op=False, role="KV"):
+        """gather_halo_into for several (X_own, X_ext) pairs as one grouped exchange (K | V)."""
+        n_own = self.n_own
+        bufs = []
+        for j, (X_own, X_ext) in enumerate(pairs):
+            if not (X_own.data_ptr() == X_ext.data_ptr() and X_own.is_contiguous()):
+                X_ext[:n_own].copy_(X_own)
+            bufs.append((X_ext[n_own:], self._pack(X_own, role + str(j))))
+        return self._timed("halo_" + role, lambda: self._all_to_all_group(bufs, self.recv_counts, self.send_counts, async_op))
 
     def gather_halo_into(self, X_own, X_ext, async_op=False, role="x"):
         """X_ext[:n_own] = X_own; X_ext[n_own:] = rows of X for the halo nodes, fetched from their
@@ -339,12 +447,21 @@ class ShardedAttention:
         # started at once; the V rows are only awaited in front of the SpMM, so that exchange
         # runs under the SDDMM and the softmax.
         K_ext, V_ext = self._ext_buffer("K", Kd), self._ext_buffer("V", Vd)
-        wait_k = self.gather_halo_into(Kd, K_ext, async_op=True, role="K")
-        wait_v = self.gather_halo_into(Vd, V_ext, async_op=True, role="V")
+        self.collectives_last_step = 0
+        row_bytes = Kd[0].numel() * Kd.element_size() if Kd.size(0) else 0
+        if self._pack_kv_now(row_bytes):
+            wait_k = wait_v = self.gather_halos_grouped([(Kd, K_ext), (Vd, V_ext)], async_op=True)
+        else:
+            wait_k = self.gather_halo_into(Kd, K_ext, async_op=True, role="K")
+            wait_v = self.gather_halo_into(Vd, V_ext, async_op=True, role="V")
         a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
         a8 = g.csr_args()
-        wait_k.wait()
-        s = ops.maskedmm_csr_forward(*a4, Qd, K_ext)
+        if self.fwd_halves is not None:
+            # own-column half while the K rows travel (it gathers K_ext[:n_own] only), halo-column half behind the wait
+            s = self._sddmm_forward_halves(Qd, K_ext, wait_k)
+        else:
+            wait_k.wait()
+            s = ops.maskedmm_csr_forward(*a4, Qd, K_ext)
         a = ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, s)
         wait_v.wait()
         if self.ops is None and V_ext.is_cuda:
@@ -392,7 +509,37 @@ class ShardedAttention:
         for t, gr in ((Q, dQ), (K, dK), (V, dV)):
             if t.requires_grad:
                 t.grad = gr
+        if self.ops is None and dQ.is_cuda:
+            from . import _lib
+            _lib.check_errors(sync=False)     # a device-side abort of a finished launch is raised before the gradients leave
         return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    def _sddmm_forward_halves(self, Q, K_ext, wait_k):
+        """s = SDDMM(Q, K_ext) as two launches over disjoint slot sets that share s: own columns first (no halo row is
+        read: runs under the K exchange), then wait, then the halo columns.  Every score is written once: no fill, no add."""
+        g, (own, halo) = self.graph, self.fwd_halves
+        h = Q.size(1) if Q.dim() == 3 else 1
+        s = Q.new_empty((g.n_edges,) if h == 1 else (g.n_edges, h))
+        if self.ops is None and Q.is_cuda:
+            from . import _lib
+            L = _lib.lib()
+            with _lib.device_guard(Q.device):
+                for half in (own, halo):
+                    if half is halo:
+                        wait_k.wait()
+                    _lib.check(L.graphop_maskedmm_csr_forward_partial(
+                        _lib.dtype_code(Q), _lib.ptr(half["row"]), _lib.ptr(half["ptr"]), _lib.ptr(half["slots"]),
+                        _lib.ptr(half["indices"]), _lib.ptr(Q), _lib.ptr(K_ext), _lib.ptr(s), half["row"].size(0),
+                        half["slots"].size(0), g.n_edges, Q.size(0), K_ext.size(0), h, Q.size(-1), _lib.stream_of(Q)))
+            return s
+        # reference surface (fresh output per call): each half computes its own score array, copied to its slots
+        ops = self._ops()
+        for half in (own, halo):
+            if half is halo:
+                wait_k.wait()
+            if half["slots"].numel():
+                s[half["slots"]] = ops.maskedmm_csr_forward(half["row"], half["ptr"], half["eid_local"], half["indices"], Q, K_ext)
+        return s
 
     # ---- C-ABI calls the reference's Python surface cannot express (HIP path only) -----------------
     def _spmm_forward_own_rows(self, a, V_ext):
@@ -455,23 +602,25 @@ class ShardedAttention:
                 "send_rows_per_peer": list(self.send_counts),
                 "bytes_per_exchange_in": self.n_halo * row_bytes,
                 "bytes_per_exchange_out": int(self.serve_rows.numel()) * row_bytes,
-                "exchanges_per_step": 4}
+                "exchanges_per_step": 4, "collectives_last_step": self.collectives_last_step,
+                "kv_packed": self._pack_kv_now(row_bytes), "forward_split": self.fwd_halves is not None}
 
     # ---- builders --------------------------------------------------------------------------------
     @classmethod
     def from_global_coo(cls, src, dst, n_nodes, rank, world, device, chunk_size=32, ops=None, group=None,
-                        force_collectives=False, halo_mask=None):
+                        force_collectives=False, halo_mask=None, **kw):
         """Every rank holds the full edge list (small graphs / tests); ranges balanced by edges."""
         deg = torch.bincount(src.to(torch.int64), minlength=n_nodes)
         bounds = balanced_ranges(deg, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         m = (src >= lo) & (src < hi)
         return cls(rank, world, bounds, src[m], dst[m], device, chunk_size, ops, group,
-                   force_collectives=force_collectives, halo_mask=None if halo_mask is None else halo_mask.to(m.device)[m])
+                   force_collectives=force_collectives, halo_mask=None if halo_mask is None else halo_mask.to(m.device)[m],
+                   **kw)
 
     @classmethod
     def synthetic(cls, n_per_rank, e_per_rank, world, rank, device, alpha=0.5, seed=0, chunk_size=32,
-                  ops=None, group=None, timing_only=False, cut=1.0, force_collectives=False, self_halo=False):
+                  ops=None, group=None, timing_only=False, cut=1.0, force_collectives=False, self_halo=False, **kw):
         """Weak-scaling bench graph: `world` equal node ranges of a Chung-Lu graph with
         world*n_per_rank nodes; each rank draws the e_per_rank edges of its own rows on its own
         device.  Sources come from its range; a destination comes from the GLOBAL weight vector with
@@ -509,11 +658,11 @@ class ShardedAttention:
             dsts.append(d_glob)
         return cls(rank, world, bounds, torch.cat(srcs), torch.cat(dsts), device, chunk_size, ops, group,
                    timing_only, force_collectives=force_collectives,
-                   halo_mask=torch.cat(glob) if self_halo else None)
+                   halo_mask=torch.cat(glob) if self_halo else None, **kw)
 
     @classmethod
     def synthetic_rmat(cls, scale, e_per_rank, world, rank, device, seed=0, chunk_size=32, ops=None,
-                       group=None, timing_only=False):
+                       group=None, timing_only=False, **kw):
         """High-degree-row stress graph (BASELINE.json config 5): equal node ranges of an R-MAT graph
         on 2**scale nodes; each rank draws e_per_rank edges whose sources lie in its range
         (graphs.rmat_edges with the range's bit prefix).  NB an R-MAT graph cut into equal node
@@ -525,4 +674,4 @@ class ShardedAttention:
         bounds = [p * n_per_rank for p in range(world + 1)]
         src, dst = graphs.rmat_edges(scale, e_per_rank, seed + 7919 * (rank + 1), device, src_prefix_bits=bits,
                                      src_prefix=rank)
-        return cls(rank, world, bounds, src, dst, device, chunk_size, ops, group, timing_only)
+        return cls(rank, world, bounds, src, dst, device, chunk_size, ops, group, timing_only, **kw)

@@ -7,6 +7,7 @@ package's HIP ops instead of the CUDA extension.
 """
 from torch.autograd import Function
 
+from . import _lib
 from . import graphop as _ops
 
 
@@ -120,6 +121,7 @@ def fused_attention_step(g, Q, K, V, dO):
     """The same fwd+bwd as attention_step through the fused op; returns o."""
     o = FusedAttention.apply(*g.csr_args(), Q, K, V)
     o.backward(dO)
+    _lib.check_errors(sync=False)     # as in attention_step
     return o
 
 
@@ -132,4 +134,7 @@ def attention_step(g, Q, K, V, dO):
     a = SparseSoftmax.apply(g.row, g.ptr_r, g.eid_r, s)
     o = VectorSPMM.apply(*args, a, V)
     o.backward(dO)
+    # a device-side abort (include/graphop_hip.h: graphop_check_device_errors) of a launch that has already finished is
+    # raised HERE, before the gradients leave the step; one still in flight is sticky and fails the next op call
+    _lib.check_errors(sync=False)
     return s, a, o

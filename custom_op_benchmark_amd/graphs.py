@@ -103,24 +103,38 @@ def uniform_random_graph(n_nodes, n_edges, seed=0, chunk_size=32, device="cpu", 
     return graph_from_coo(src, dst, n_nodes, n_dst, chunk_size)
 
 
-def powerlaw_weights(n_nodes, alpha, seed, device):
+def powerlaw_weights(n_nodes, alpha, seed, device, shuffle=True):
     """Chung-Lu node weights w_i ~ (rank_i + r0)^-alpha with node ids shuffled, so hubs
-    are not clustered by id.  alpha=0 is uniform."""
+    are not clustered by id (shuffle=False: ids sorted by degree, hubs first).  alpha=0 is uniform."""
     g = torch.Generator(device=device).manual_seed(seed)
     rank = torch.arange(n_nodes, dtype=torch.float64, device=device)
     w = (rank + 10.0).pow(-alpha)
     perm = torch.randperm(n_nodes, generator=g, device=device)
+    if not shuffle:
+        return w / w.sum()
     out = torch.empty_like(w)
     out[perm] = w
     return out / out.sum()
 
 
+LABELINGS = ("shuffled", "degree", "clustered")
+
+
 def chung_lu_graph(n_nodes, n_edges, alpha=0.5, seed=0, chunk_size=32, device="cpu",
-                   batch=1 << 26):
+                   batch=1 << 26, labeling="shuffled", community=1024, p_in=0.9):
     """Reddit-shape stand-in: both endpoints of every edge drawn from one power-law node
     weight vector (expected degree of node i = E * w_i on both sides), sampled on
-    ``device`` by inverse-CDF search in batches."""
-    w = powerlaw_weights(n_nodes, alpha, seed, device)
+    ``device`` by inverse-CDF search in batches.
+    labeling (how node ids relate to the structure; the kernels must not care -- bench.py --labeling):
+      "shuffled"   hubs spread uniformly over the ids (the default);
+      "degree"     ids sorted by expected degree, hubs first (what a degree-ordered real graph looks like);
+      "clustered"  stochastic-block communities of `community` consecutive ids: an edge's destination lies in its
+                   source's community with probability p_in (drawn by weight inside it), anywhere otherwise --
+                   the generalisation of the reference's own fixture (wrapper.py:84-112: disjoint complete blocks,
+                   i.e. p_in = 1 at community = 30); hubs are spread over the communities."""
+    if labeling not in LABELINGS:
+        raise ValueError("labeling must be one of %s" % (LABELINGS,))
+    w = powerlaw_weights(n_nodes, alpha, seed, device, shuffle=(labeling != "degree"))
     cdf = torch.cumsum(w, 0)
     cdf[-1] = 1.0
     g = torch.Generator(device=device).manual_seed(seed + 1)
@@ -128,9 +142,20 @@ def chung_lu_graph(n_nodes, n_edges, alpha=0.5, seed=0, chunk_size=32, device="c
     for s in range(0, n_edges, batch):
         m = min(batch, n_edges - s)
         u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
-        srcs.append(torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1))
+        src = torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1)
         u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
-        dsts.append(torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1))
+        dst = torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1)
+        if labeling == "clustered":
+            lo = (src // community) * community
+            hi = (lo + community).clamp_(max=n_nodes)
+            c_lo = torch.where(lo > 0, cdf[(lo - 1).clamp_(min=0)], torch.zeros((), dtype=cdf.dtype, device=device))
+            c_hi = cdf[hi - 1]
+            u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+            inside = torch.searchsorted(cdf, c_lo + u * (c_hi - c_lo)).clamp_(max=n_nodes - 1)
+            inside = torch.minimum(torch.maximum(inside, lo), hi - 1)
+            keep = torch.rand(m, generator=g, device=device) < p_in
+            dst = torch.where(keep, inside, dst)
+        srcs.append(src); dsts.append(dst)
     src, dst = torch.cat(srcs), torch.cat(dsts)
     del srcs, dsts
     return graph_from_coo(src, dst, n_nodes, n_nodes, chunk_size)

@@ -20,14 +20,23 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, h, d, out_dir):
+def _worker(rank, world, port, h, d, out_dir, pack_kv, split_forward):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
         inp = rand_inputs(g, h, d, seed=22, normal=True)
-        sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle)
+        sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle,
+                                              pack_kv=pack_kv, split_forward=split_forward)
+        assert (sh.fwd_halves is not None) == (split_forward and sh.n_halo > 0)
+        if sh.fwd_halves is not None:
+            # the two halves cut the row-major slots into disjoint sets that cover all of them, own columns / halo columns
+            own, halo = sh.fwd_halves
+            both = torch.cat([own["slots"], halo["slots"]])
+            assert torch.equal(torch.sort(both).values, torch.arange(sh.graph.n_edges))
+            assert bool((own["indices"] < sh.n_own).all()) and bool((halo["indices"] >= sh.n_own).all())
+            assert int(own["ptr"][-1]) == own["slots"].numel() and int(halo["ptr"][-1]) == halo["slots"].numel()
         lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
         # index maps: local column ids map back to the global ids exactly
         ext_ids = torch.cat([torch.arange(lo, hi), sh.halo_ids])
@@ -38,6 +47,7 @@ def _worker(rank, world, port, h, d, out_dir):
         assert torch.equal(torch.sort(key_local).values, torch.sort(key_global).values)
         assert sum(sh.recv_counts) == sh.n_halo and sh.recv_counts[rank] == 0
         r = sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
+        assert sh.collectives_last_step == (3 if pack_kv else 4)     # K | V as one grouped exchange, or K and V; dV; dK
         torch.save({k: v for k, v in r.items()} | {"lo": lo, "hi": hi, "edge_mask": m, "key": key_local},
                    os.path.join(out_dir, "r%d.pt" % rank))
         dist.barrier()
@@ -45,10 +55,12 @@ def _worker(rank, world, port, h, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,d", [(2, 1, 16), (3, 2, 8)])
-def test_sharded_step_matches_single_process(tmp_path, world, h, d):
+@pytest.mark.parametrize("world,h,d,pack_kv,split_forward", [(2, 1, 16, False, True), (3, 2, 8, True, True), (2, 2, 8, True, False)])
+def test_sharded_step_matches_single_process(tmp_path, world, h, d, pack_kv, split_forward):
+    """(round 5) split_forward: the SDDMM forward as an own-column half under the K exchange + a halo-column half behind
+    it, both writing the one score array; pack_kv: K | V halo rows as one grouped exchange (batch_isend_irecv)."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, h, d, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, h, d, str(tmp_path), pack_kv, split_forward), nprocs=world, join=True)
     g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
     inp = rand_inputs(g, h, d, seed=22, normal=True)
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
@@ -96,7 +108,7 @@ def test_local_group_shards_match_single_process(world):
 
     def shard(rank, handle):
         sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle,
-                                              group=handle)
+                                              group=handle, pack_kv=(world == 4))
         lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
         K, V = inp["K"][lo:hi], inp["V"][lo:hi]
         if world == 4:      # the caller keeps its K / V rows inside the extended buffers: no own-row copy per exchange
@@ -129,7 +141,7 @@ def test_rmat_shard_edges_stay_in_range():
     assert abs(float((d2 < 512).float().mean()) - 0.76) < 0.02
 
 
-def _self_halo_worker(rank, world, port, out_dir):
+def _self_halo_worker(rank, world, port, out_dir, pack_kv):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -137,14 +149,18 @@ def _self_halo_worker(rank, world, port, out_dir):
         g = random_graph(97, 97, 2500, seed=21, chunk_size=8, zero_rows=0.1, hub=300)
         inp = rand_inputs(g, 2, 8, seed=22, normal=True)
         mask = torch.rand(g.src.numel(), generator=torch.Generator().manual_seed(5)) < 0.5
-        calls = []
-        real = dist.all_to_all_single
+        calls, groups = [], []
+        real, real_b = dist.all_to_all_single, dist.batch_isend_irecv
         dist.all_to_all_single = lambda *a, **k: (calls.append(bool(k.get("async_op"))), real(*a, **k))[1]
+        dist.batch_isend_irecv = lambda ops: (groups.append(len(ops)), real_b(ops))[1]
         sh = ShardedAttention.from_global_coo(g.src, g.dst, g.n_src, rank, world, "cpu", chunk_size=8, ops=oracle,
-                                              force_collectives=True, halo_mask=mask)
+                                              force_collectives=True, halo_mask=mask, pack_kv=pack_kv)
         assert sh.n_halo > 0 and sh.recv_counts == [sh.n_halo] and len(calls) == 2
         r = sh.step(inp["Q"], inp["K"], inp["V"], inp["dO"])
-        assert len(calls) == 6 and all(calls[2:])           # K, V, dV, dK went through the process group, async
+        if pack_kv:     # K | V: one grouped exchange (gloo has no send-to-self: the own segment is a copy, the group is empty)
+            assert len(calls) == 4 and all(calls[2:]) and sh.collectives_last_step == 3
+        else:
+            assert len(calls) == 6 and all(calls[2:]) and not groups    # K, V, dV, dK went through the process group, async
         want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
         for k in ("o", "dQ", "dK", "dV"):
             torch.testing.assert_close(r[k], want[k], rtol=1e-4, atol=1e-5)
@@ -153,11 +169,12 @@ def _self_halo_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_forced_collectives_at_world_size_one(tmp_path):
+@pytest.mark.parametrize("pack_kv", [False, True])
+def test_forced_collectives_at_world_size_one(tmp_path, pack_kv):
     """force_collectives: a one-rank process group still goes through all_to_all_single (no world == 1 short-cut),
     and a self-halo (halo_mask) makes the exchanges move real rows: the CPU twin of
     tests/test_dist_gpu.py::test_rccl_path_at_world_size_one."""
-    mp.spawn(_self_halo_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_self_halo_worker, args=(1, _free_port(), str(tmp_path), pack_kv), nprocs=1, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok"))
 
 

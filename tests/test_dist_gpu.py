@@ -75,6 +75,40 @@ def test_sharded_hip_step_window_drivers(dev, world):
         _lib.tune_reset(); _lib.clear_plan_cache()
 
 
+def test_partial_sddmm_entry_composes_one_score_array(dev):
+    """graphop_maskedmm_csr_forward_partial (ABI 7): two chunk lists over disjoint slot sets write ONE score array, no zero
+    fill (entries no list names keep what they held), each named entry written once -- vs the oracle's full SDDMM."""
+    import ctypes
+    for h, d in ((1, 64), (2, 16), (1, 20)):
+        g = random_graph(300, 400, 9000, seed=3 + h, chunk_size=8, zero_rows=0.1, hub=500)
+        inp = rand_inputs(g, h, d, seed=4, normal=True)
+        want = oracle.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, inp["Q"], inp["K"])
+        gd = g.to(dev)
+        Q, K = inp["Q"].to(dev), inp["K"].to(dev)
+        from custom_op_benchmark_amd.part_csr import partition_csr
+        pick = torch.rand(g.n_edges, generator=torch.Generator().manual_seed(9)) < 0.6
+        s = torch.full(want.shape, float("nan"), device=dev)
+        untouched = torch.zeros(g.n_edges, dtype=torch.bool)
+        for k, mask in enumerate((pick, ~pick)):
+            if k == 1:
+                mask = mask & (torch.arange(g.n_edges) % 7 != 0)      # leave some entries to nobody
+                untouched = ~(pick | mask)
+            m = mask.to(dev)
+            cum = torch.zeros(g.n_edges + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(m, 0, out=cum[1:])
+            ip = cum[gd.indptr_r].contiguous()
+            slots = torch.nonzero(m).flatten()
+            row, ptr_ = partition_csr(ip, 8)
+            idx = gd.indices_r[slots].contiguous()
+            _lib.check(_lib.lib().graphop_maskedmm_csr_forward_partial(
+                _lib.dtype_code(Q), _lib.ptr(row), _lib.ptr(ptr_), _lib.ptr(slots), _lib.ptr(idx), _lib.ptr(Q), _lib.ptr(K),
+                _lib.ptr(s), row.size(0), slots.size(0), g.n_edges, Q.size(0), K.size(0), h, d, _lib.stream_of(Q)))
+        torch.cuda.synchronize()
+        got = s.cpu()
+        assert bool(torch.isnan(got[untouched]).all()) and untouched.any()
+        torch.testing.assert_close(got[~untouched], want[~untouched], rtol=1e-4, atol=1e-5)
+
+
 def test_pack_and_scatter_add_kernels(dev):
     gen = torch.Generator(device=dev).manual_seed(0)
     for shape, dt in (((50, 64), torch.float32), ((50, 3, 5), torch.float32), ((40, 8, 16), torch.float64)):
@@ -137,26 +171,36 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
 assert dist.get_backend() == "nccl"
-calls = {"n": 0, "async": 0}
-real = dist.all_to_all_single
+calls = {"n": 0, "async": 0, "groups": 0, "p2p": 0}
+real, real_b = dist.all_to_all_single, dist.batch_isend_irecv
 def counted(*a, **k):
     calls["n"] += 1; calls["async"] += 1 if k.get("async_op") else 0
     return real(*a, **k)
+def counted_b(ops):
+    calls["groups"] += 1; calls["p2p"] += len(ops)
+    return real_b(ops)
 dist.all_to_all_single = counted
-for h, d in ((1, 64), (2, 16)):
+dist.batch_isend_irecv = counted_b
+for h, d, pack in ((1, 64, False), (2, 16, True)):
     g = random_graph(600, 600, 20000, seed=31 + h, chunk_size=8, zero_rows=0.1, hub=700)
     inp = rand_inputs(g, h, d, seed=32, normal=True)
     want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
     mask = torch.rand(g.src.numel(), generator=torch.Generator().manual_seed(5)) < 0.5   # half of the edges: fetched through RCCL
     n0 = calls["n"]
     sh = ShardedAttention.from_global_coo(g.src.to(dev), g.dst.to(dev), g.n_src, 0, 1, dev, chunk_size=8,
-                                          force_collectives=True, halo_mask=mask)
+                                          force_collectives=True, halo_mask=mask, pack_kv=pack)
     assert sh.n_halo > 0 and sh.recv_counts == [sh.n_halo] and sh.send_counts == [sh.n_halo]
+    assert sh.fwd_halves is not None                 # SDDMM forward = own-column half under the K exchange + halo-column half
     assert calls["n"] - n0 == 2                      # setup: counts, then the id lists -- through the process group
-    n0, a0 = calls["n"], calls["async"]
+    n0, a0, g0, p0 = calls["n"], calls["async"], calls["groups"], calls["p2p"]
     r = sh.step(*(inp[k].to(dev) for k in ("Q", "K", "V", "dO")))
     torch.cuda.synchronize()
-    assert calls["n"] - n0 == 4 and calls["async"] - a0 == 4, calls     # K, V, dV, dK: asynchronous RCCL all-to-alls
+    if pack:    # K | V as ONE grouped RCCL exchange (send + recv to self for each table), then dV, dK
+        assert calls["n"] - n0 == 2 and calls["async"] - a0 == 2 and calls["groups"] - g0 == 1 and calls["p2p"] - p0 == 4, calls
+        assert sh.collectives_last_step == 3
+    else:       # K, V, dV, dK: asynchronous RCCL all-to-alls
+        assert calls["n"] - n0 == 4 and calls["async"] - a0 == 4 and calls["groups"] == g0, calls
+        assert sh.collectives_last_step == 4
     ext_ids = torch.cat([torch.arange(0, g.n_src, device=dev), sh.halo_ids])
     key = (sh.graph.src * g.n_dst + ext_ids[sh.graph.dst]).cpu()
     order = torch.argsort(key, stable=True)
@@ -198,5 +242,7 @@ def test_bench_line_through_the_rccl_path(dev):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     cfg = line["config"]
     assert cfg["backend"] == "nccl" and cfg["world_size"] == 1 and cfg["halo"]["n_halo"] > 0
-    assert cfg["halo"]["exchange_ms_is_local_copy"] is False and set(cfg["halo"]["exchange_ms"]) == {"halo_K", "halo_V", "grad_dV", "grad_dK"}
+    fwd = {"halo_KV"} if cfg["halo"]["kv_packed"] else {"halo_K", "halo_V"}
+    assert cfg["halo"]["exchange_ms_is_local_copy"] is False and set(cfg["halo"]["exchange_ms"]) == fwd | {"grad_dV", "grad_dK"}
+    assert cfg["halo"]["forward_split"] is True and "exposed_exchange_ms" in line and line["exposed_exchange_ms"] is not None
     assert line["value"] > 0 and line["n_gpus"] == 1

@@ -300,3 +300,52 @@ def test_rmat25_shard_properties(dev):
     deg = sh.graph.indptr_r[1:] - sh.graph.indptr_r[:-1]
     assert int(deg.max()) > 100_000, int(deg.max())
     _shard_property_battery(dev, sh, 256)
+
+
+def test_cora_shape_vs_oracle_unfused_and_fused(dev):
+    """BASELINE config 1's shape (Cora: N = 2,708, E = 10,556, d = 64, 1 head) at the default knobs against the C oracle,
+    through the 8-function step and through the fused op (round-4 verdict, item 7: only smoke() ran this shape)."""
+    import oracle
+    from util import oracle_step
+    g = graphs.chung_lu_graph(2708, 10556, alpha=0.5, seed=0)
+    gen = torch.Generator().manual_seed(1)
+    Q, K, V, dO = (torch.rand(2708, 64, generator=gen) for _ in range(4))
+    want = oracle_step(oracle, g, Q, K, V, dO)
+    gd = g.to(dev)
+    q, k, v = (x.to(dev).requires_grad_(True) for x in (Q, K, V))
+    s, a, o = functions.attention_step(gd, q, k, v, dO.to(dev))
+    tol = dict(rtol=1e-4, atol=1e-5)
+    for name, got in (("s", s), ("a", a), ("o", o), ("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
+        torch.testing.assert_close(got.detach().cpu(), want[name], msg=lambda m: name + ": " + m, **tol)
+    q2, k2, v2 = (x.to(dev).requires_grad_(True) for x in (Q, K, V))
+    o2 = functions.fused_attention_step(gd, q2, k2, v2, dO.to(dev))
+    for name, got in (("o", o2), ("dQ", q2.grad), ("dK", k2.grad), ("dV", v2.grad)):
+        torch.testing.assert_close(got.detach().cpu(), want[name], msg=lambda m: "fused " + name + ": " + m, **tol)
+
+
+@pytest.mark.parametrize("labeling", ["shuffled", "degree", "clustered"])
+def test_labelings_default_geometry_vs_cpu_path(dev, labeling):
+    """The same generator under the three node labelings of bench.py --labeling (hubs spread over the ids / ids sorted by
+    degree / communities of consecutive ids) at the DEFAULT geometry -- window, walk and softmax drivers as the bench runs
+    them -- against the stock-PyTorch CPU path.  Results must not depend on how ids relate to the structure."""
+    N, E, d = 40000, 12_000_000, 64
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=4, device=dev, labeling=labeling, community=512)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    Q, K, V, dO = (torch.randn(N, d, device=dev, generator=gen) / 8 for _ in range(4))
+    q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    _lib.profile_enable(True)
+    functions.attention_step(g, q, k, v, dO)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["spmm_fwd"]["kernel"] == "k_spmm_walk_f32" and prof["sddmm_fwd"]["kernel"].startswith("k_sddmm_wown"), prof
+    o0, dQ0, dK0, dV0 = torch_path.attention_step_blocked(g.src.cpu(), g.dst.cpu(), g.indptr_r.cpu(), Q.cpu(), K.cpu(),
+                                                          V.cpu(), dO.cpu(), N, rows_per_block=2048)
+    tol = dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(q.grad.cpu(), dQ0, **tol)
+    torch.testing.assert_close(k.grad.cpu(), dK0, **tol)
+    torch.testing.assert_close(v.grad.cpu(), dV0, **tol)
+    q2, k2, v2 = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    o2 = functions.fused_attention_step(g, q2, k2, v2, dO)
+    torch.testing.assert_close(o2.detach().cpu(), o0, **tol)
+    torch.testing.assert_close(k2.grad.cpu(), dK0, **tol)

@@ -171,10 +171,49 @@ def test_hand_over_timeout_is_an_error_not_a_wrong_result(dev, force_walk, fault
     torch.cuda.synchronize()
     _lib.tune("walk_fault", 0)
     with pytest.raises(RuntimeError, match="walk kernel"):
-        ops.vector_spmm_forward(*a4, a, V)            # ... here: the entry point checks the word before launching
-    again = ops.vector_spmm_forward(*a4, a, V)        # the word was cleared by the report
+        ops.vector_spmm_forward(*a4, a, V)            # ... here: the entry point checks the record before launching
+    # ABI 7: the record is STICKY -- an entry point reports it but does not clear it (a thread that ignores a return
+    # code must not swallow the failure for everybody else); the message names the pass and the device
+    with pytest.raises(RuntimeError, match=r"pass 'spmm_fwd' on device \d+, walk launch #\d+"):
+        ops.vector_spmm_forward(*a4, a, V)
+    with pytest.raises(RuntimeError, match="sticky"):
+        ops.sparse_softmax_forward(g.row, g.ptr_r, g.eid_r, a)     # any op, not only the walk's
+    with pytest.raises(RuntimeError, match=what):
+        _lib.check_errors(sync=False)                 # graphop_check_device_errors: reports AND clears
+    again = ops.vector_spmm_forward(*a4, a, V)        # acknowledged: the library works again
     _lib.check_errors()
     torch.testing.assert_close(again, good, rtol=1e-5, atol=1e-6)
+
+
+def test_step_exit_reports_an_abort_of_its_own_launches(dev, force_walk):
+    """functions.attention_step looks at the device error record on its way out (round-4 advice: an abort in the LAST
+    launch of a step was only reported by the next graphop call, after an optimizer could have consumed the gradients).
+    The check does not synchronise: an abort that has already landed is raised by this step, one still in flight by
+    the next call at the latest (sticky)."""
+    from custom_op_benchmark_amd import functions
+    _lib.tune("walk_blocks", 8)
+    g = random_graph(1500, 1500, 30000, seed=21, chunk_size=32, hub=900).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(6)
+    Q, K, V, dO = (torch.randn(1500, 64, device=dev, generator=gen) for _ in range(4))
+    for t in (Q, K, V):
+        t.requires_grad_(True)
+    functions.attention_step(g, Q, K, V, dO)
+    _lib.check_errors()
+    _lib.tune("walk_fault", 1)
+    try:
+        with pytest.raises(RuntimeError, match="walk kernel"):
+            functions.attention_step(g, Q, K, V, dO)          # spmm_fwd aborts early in the step: a later op or the exit check raises
+            torch.cuda.synchronize()
+            functions.attention_step(g, Q, K, V, dO)          # (if the first step's launches were all still in flight)
+    finally:
+        _lib.tune("walk_fault", 0)
+        torch.cuda.synchronize()
+        try:
+            _lib.check_errors()
+        except RuntimeError:
+            pass
+    functions.attention_step(g, Q, K, V, dO)
+    _lib.check_errors()
 
 
 def kernels_by_tag(step):

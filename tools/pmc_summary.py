@@ -13,7 +13,7 @@ import os
 import sys
 
 
-def load(path):
+def load(path, by_dispatch=None):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
@@ -21,6 +21,11 @@ def load(path):
             continue
         short = name.split("graphop::")[1].split("(")[0]
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if by_dispatch is not None and r.get("Dispatch_Id"):
+            # per kernel FAMILY (template arguments stripped: what bench.py's pass records name) in dispatch order,
+            # so that tools/make_traffic_json.py can tell the launches of one step apart (round-4 advice)
+            fam = short.split("<")[0]
+            by_dispatch[fam][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return acc
 
 
@@ -28,11 +33,12 @@ def main():
     d = sys.argv[1]
     prefixes = sys.argv[2:] or ["fetch", "write", "l2"]
     out = collections.defaultdict(dict)
+    by_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in prefixes:
         f = os.path.join(d, p + "_counter_collection.csv")
         if not os.path.exists(f):
             continue
-        for k, cs in load(f).items():
+        for k, cs in load(f, by_dispatch).items():
             for c, vals in cs.items():
                 out[k][c] = sum(vals) / len(vals)
                 out[k]["launches_seen"] = len(vals)
@@ -44,6 +50,17 @@ def main():
             v["write_bytes"] = v["WRITE_SIZE"] * 1024
         if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
             v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    # a counter summed over the shader engines / XCDs appears once per dispatch in the CSV; if it appears several
+    # times (one row per dimension) the rows of one dispatch are added up
+    seq = {}
+    for fam, cs in by_dispatch.items():
+        seq[fam] = {}
+        for c, pairs in cs.items():
+            per = collections.OrderedDict()
+            for did, v in sorted(pairs):
+                per[did] = per.get(did, 0.0) + v
+            seq[fam][c] = list(per.values())
+    out["__by_dispatch__"] = seq
     print(json.dumps(out, indent=1, sort_keys=True))
 
 

@@ -18,15 +18,15 @@ cp "$(find "$OUT/prof_$TAG" -name 'stats_kernel_stats.csv' | head -1)" "$OUT/${T
 echo "[refresh] kernel stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$TAG" -o $c -- \
-      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pmc_$c.log" 2>&1
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fused --profile-steps 1 > "$OUT/pmc_$c.log" 2>&1
   echo "[refresh] pmc $c done"
 done
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --output-format csv -d "$OUT/pmc_$TAG" -o l2 -- \
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pmc_l2.log" 2>&1
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fused --profile-steps 1 > "$OUT/pmc_l2.log" 2>&1
 echo "[refresh] pmc l2 done"
 python tools/pmc_summary.py "$(dirname "$(find "$OUT/pmc_$TAG" -name 'l2_counter_collection.csv' | head -1)")" \
     FETCH_SIZE WRITE_SIZE l2 > "$OUT/${TAG}_pmc_summary.json"
-python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 > "$OUT/${TAG}_pmc_traffic.json"
+python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 "$OUT/pmc_WRITE_SIZE.log" > "$OUT/${TAG}_pmc_traffic.json"
 # the headline line AFTER the counter passes: bench.py quotes roofline.traffic from profiles/pmc_traffic.json when
 # that file was measured on the same kernel sources (copy the new one into profiles/ afterwards)
 cp "$OUT/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json
