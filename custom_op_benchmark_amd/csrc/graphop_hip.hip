@@ -642,6 +642,7 @@ namespace {
 template <int L, int NV>
 int try_sddmm_sweep(const char* tag, int dtype, const graphop_plan* plan, i64 n_table_rows, const void* A,
                     const void* B, void* y, i64 h, int d4, hipStream_t st) {
+  if (!plan) return 0;   // (plan-less calls -- the C ABI allows them, the partial SDDMM entry always makes them -- take the chunk drivers)
   SweepLaunch sl;
   SweepOpts so;
   const bool f64 = dtype == GRAPHOP_F64;

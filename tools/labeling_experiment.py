@@ -14,10 +14,15 @@ ap.add_argument("--d", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--cases", default="ss,dd,ds,sd")
 ap.add_argument("--fused", action="store_true")
+ap.add_argument("--tune", default="", help="knob=value,... applied before every case (graphop_tune)")
+ap.add_argument("--graph", default="chung_lu", help="chung_lu | clustered (graphs.chung_lu_graph labeling)")
 args = ap.parse_args()
+for kv in filter(None, args.tune.split(",")):
+    k, v = kv.split("=")
+    _lib.tune(k, int(v))
 dev = torch.device("cuda:0")
 N, E = graphs.SHAPES["reddit"]
-g0 = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev)
+g0 = graphs.chung_lu_graph(N, E, alpha=0.5, seed=0, device=dev, labeling="clustered" if args.graph == "clustered" else "shuffled")
 deg_r = g0.indptr_r[1:] - g0.indptr_r[:-1]
 deg_c = g0.indptr_c[1:] - g0.indptr_c[:-1]
 
@@ -49,7 +54,7 @@ for case in args.cases.split(","):
     for _ in range(args.steps): step()
     t1.record(); torch.cuda.synchronize()
     prof = _lib.profile_read(); _lib.profile_enable(False)
-    print("rows %-8s cols %-8s d=%d step %.2f ms |" % ("degree" if case[0] == "d" else "shuffled", "degree" if case[1] == "d" else "shuffled",
+    print("[%s] rows %-8s cols %-8s d=%d step %.2f ms |" % (args.tune or "defaults", "degree" if case[0] == "d" else "shuffled", "degree" if case[1] == "d" else "shuffled",
                                                      args.d, t0.elapsed_time(t1) / args.steps),
           " ".join("%s %.2f" % (k, v["mean_ms"]) for k, v in prof.items() if k != "zero_fill"), flush=True)
     del g, Q, K, V, dO
