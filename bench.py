@@ -385,6 +385,7 @@ def main():
         total_edges = g.n_edges
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_edges * args.steps / elapsed
+    plan_mb_step = _lib.plan_memory_bytes() / 2**20      # what the 8-function step alone keeps (before the fused op builds its layouts)
 
     # sharded lines: what the exchanges cost the step = this step - the same step with every exchange a no-op (nothing
     # is packed, sent, awaited or added; values involving halo rows are garbage: timing only), measured the same way
@@ -657,7 +658,10 @@ def main():
                     "max": round(max(step_ms), 4), "method": "hipEvents around every timed step on the launch stream"},
         "config": cfg,
         "setup": {"graph_build_s": round(t_graph, 2), "first_step_with_plans_s": round(t_first, 3),
-                  "plan_memory_MB": round(_lib.plan_memory_bytes() / 2**20, 1)},
+                  "plan_memory_MB": round(_lib.plan_memory_bytes() / 2**20, 1),
+                  "plan_memory_MB_8_function_step": round(plan_mb_step, 1),
+                  "plan_memory_note": "device bytes of both orientations' plans: every layout of the 8-function step AND (plan_memory_MB) "
+                                      "of the fused op measured behind it; a model uses one of the two forms"},
         "launch": "hip graph replay" if args.hip_graph else "eager API calls",
         "roofline": roofline,
     }

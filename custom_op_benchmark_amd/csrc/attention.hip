@@ -35,6 +35,7 @@ SweepOpts attn_opts(int L, int NV, bool col, bool dry_run) {
   o.window_scale = t.attn_window_scale > 0 ? t.attn_window_scale : 1;
   o.dry_run = dry_run ? 1 : 0;
   o.staged = attn_staged(L, NV) ? 1 : 0;
+  o.no_eids = 1;          // (a, ds are recomputed per slot: neither fused pass reads eid)
   o.stage_lds_per_group = (4 * L > 128 ? 4 * L : 128) * 2 * (int)sizeof(int);   // StageCfg<L, 1>::kLdsIntsPerGroup ints
   const int cap = o.staged ? attn_bpc_staged(NV, col) : attn_bpc(NV, col);
   o.bpc = (t.attn_bpc > 0 && t.attn_bpc < cap) ? t.attn_bpc : cap;

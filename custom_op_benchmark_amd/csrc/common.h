@@ -63,6 +63,7 @@ int check_not_capturing(hipStream_t st, const char* what);
 // the host looks at it at the start of every entry point and in graphop_check_device_errors (graphop_hip.hip).
 int* device_error_word(bool create);   // device-visible pointer (nullptr when there is none yet and !create)
 int check_async_error(bool clear = false);   // GRAPHOP_OK, or GRAPHOP_ERR_HIP with the message set; the record is sticky unless clear
+int tuning_plan_trim();                   // knob plan_trim (host.h: Tuning), for plan.hip
 int walk_launch_id(const char* tag);     // sequence number of the walk launch about to be made under this pass tag
 
 // ---- plan (host view) ---------------------------------------------------------------------------
@@ -92,6 +93,7 @@ struct Sweep {
   int* vr_row = nullptr;  // [V] owning row id
   int* wp_lo = nullptr;   // [W*V] first slot of vrow v inside window w
   int* wp_hi = nullptr;   // [W*V] one past its last slot inside window w
+  int runtime_wp = 0;     // sticky: a per-batch (non-staged) kernel reads wp_lo / wp_hi at run time -- plan_trim leaves them alone
   int* queues = nullptr;  // [kQueueRing][8 * 64] task-queue heads of the window-owner drivers
   unsigned queue_next = 0;  // next ring slot (taken under the plan's sweep mutex)
   // Window-major ("dealt") layouts of the window-owner tasks, one per lane-group geometry, built on
@@ -173,6 +175,7 @@ struct graphop_plan {
   int32_t* seg_e0;         // [n_segments + 1] first slot of every segment (owned, with blk_seg)
   int32_t* seg_row;        // [n_segments] row id of every segment (owned, with blk_seg)
   int device;
+  int mirrors_pinned;      // sticky: a kernel reads idx32 / eid32 at run time (per-batch window-owner kernels, block-dense kernels)
 };
 
 // ---- device-side helpers ------------------------------------------------------------------------

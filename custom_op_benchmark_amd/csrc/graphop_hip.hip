@@ -122,7 +122,7 @@ int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_
 int plan_build(graphop_plan*, i64, hipStream_t, int);
 int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
 int* plan_take_queue(graphop_plan*, const Sweep*);
-int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**);
+int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**, bool want_eids = true);
 void plan_init_sweeps(graphop_plan*);
 void plan_free_sweeps(graphop_plan*);
 int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**, bool want_widx = true);
@@ -134,6 +134,7 @@ Tuning& tuning_mut() {
   return t;
 }
 const Tuning& tuning() { return tuning_mut(); }
+int tuning_plan_trim() { return tuning().plan_trim; }
 
 // Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
 hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
@@ -258,8 +259,7 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   const Tuning& t = tuning();
   if (!t.sweep || !plan) return 0;
   const graphop_plan_info_t& pi = plan->info;
-  if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
-  if (!pi.eid_identity && !plan->eid32) return 0;
+  if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->indices) return 0;   // (has_idx32: mirrors exist or can be rebuilt)
   if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
   const i64 row_bytes = (opts && opts->row_bytes > 0) ? opts->row_bytes : 16LL * L * NV;
   const i64 table_bytes = n_table_rows * row_bytes;
@@ -326,11 +326,6 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   const i64 tiles = ceil_div(sw->V, tile);
   if (tiles * ceil_div((i64)sw->W, 8) >= 0x7fffffffLL) return 0;
   out->view = SweepView{};
-  out->view.wp_lo = sw->wp_lo;
-  out->view.wp_hi = sw->wp_hi;
-  out->view.vr_row = sw->vr_row;
-  out->view.idx32 = plan->idx32;
-  out->view.eid32 = plan->eid32;
   const bool dry = opts && opts->dry_run;
   out->view.sync = dry ? nullptr : plan_take_queue(const_cast<graphop_plan*>(plan), sw);
   out->view.V = sw->V;
@@ -345,17 +340,34 @@ int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipS
   if (nb > need) nb = need;
   out->blocks = (unsigned)(nb < 1 ? 1 : nb);
   out->lds_bytes = (size_t)gpb * K * row_bytes;
+  bool staged_ok = false;
   if (opts && opts->staged) {
     const Sweep::Dealt* dl = nullptr;
-    const int rcd = plan_get_dealt(const_cast<graphop_plan*>(plan), sw, L, K, st, &dl);
+    const int rcd = plan_get_dealt(const_cast<graphop_plan*>(plan), sw, L, K, st, &dl, /*want_eids=*/!opts->no_eids);
     if (rcd != GRAPHOP_OK) return -rcd;
     if (dl) {
       out->view.rec = (const int4*)dl->rec;
       out->view.ids_w = dl->ids;
       out->view.eids_w = dl->eids;
       out->lds_bytes += (size_t)gpb * opts->stage_lds_per_group;
+      staged_ok = pi.eid_identity || dl->eids != nullptr || opts->no_eids;   // the staged kernels read the dealt copies and nothing else
     }
   }
+  if (!staged_ok) {
+    // a per-batch kernel will read the window tables and the 32-bit mirrors at run time: resident, and kept (plan.hip)
+    const int rcp = plan_pin_sweep_tables(const_cast<graphop_plan*>(plan), sw, st);
+    if (rcp != GRAPHOP_OK) return -rcp;
+  }
+  out->view.wp_lo = sw->wp_lo;
+  out->view.wp_hi = sw->wp_hi;
+  out->view.vr_row = sw->vr_row;
+  out->view.idx32 = plan->idx32;
+  out->view.eid32 = plan->eid32;
+  plan_trim(const_cast<graphop_plan*>(plan));   // what only the builders read goes (nothing a pinned reader needs)
+  out->view.wp_lo = sw->wp_lo;                  // (staged launches: possibly NULL now -- they read rec / ids_w / eids_w only)
+  out->view.wp_hi = sw->wp_hi;
+  out->view.idx32 = plan->idx32;
+  out->view.eid32 = plan->eid32;
   return 1;
 }
 
@@ -451,8 +463,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t s
     const Tuning& t = tuning();
     if (!plan) return 0;
     const graphop_plan_info_t& pi = plan->info;
-    if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->idx32) return 0;
-    if (!pi.eid_identity && !plan->eid32) return 0;
+    if (!pi.row_owned || !plan->sorted_in_rows || !pi.has_idx32 || !plan->indices) return 0;
     if (pi.n_segments == 0 || pi.n_edges == 0) return 0;
     if (pi.max_index >= (1LL << kWalkKShift) || n_table_rows > (1LL << kWalkKShift)) return 0;   // ids share a word with the row-in-bin
     const i64 table_bytes = n_table_rows * 16LL * L * NV;
@@ -476,6 +487,7 @@ int choose_walk(const graphop_plan* plan, i64 n_table_rows, int K, hipStream_t s
     const int rc = plan_get_walk(const_cast<graphop_plan*>(plan), (int)W, ceil_div(n_table_rows, W), (int)groups, /*lane groups per bin=*/1, K,
                                  slots, st, &wk, /*want_widx=*/tables == 1);
     if (rc != GRAPHOP_OK) return -rc;
+    plan_trim(const_cast<graphop_plan*>(plan));   // the walk kernels read their own layout: the mirrors were builder input
     if (!wk) return 0;
     out->view.ids = wk->ids; out->view.widx = wk->widx; out->view.bin_pos = wk->bin_pos;
     out->view.bin_rows = wk->bin_rows; out->view.bin_cum = wk->bin_cum;
@@ -745,7 +757,7 @@ inline bool block_ok(const graphop_plan* plan, int dtype, i64 h, i64 d, i64 n_ta
   const Tuning& t = tuning();
   return t.dense_blocks && !t.force_generic && dtype == GRAPHOP_F32 && plan && plan->blk_seg &&
          plan->info.n_dense_blocks > 0 && plan->info.dense_fill_pct >= t.dense_min_fill &&
-         (plan->info.eid_identity || plan->eid32) && n_table_rows < 0x7fffffffLL &&
+         plan->idx32 && (plan->info.eid_identity || plan->eid32) && n_table_rows < 0x7fffffffLL &&
          plan->info.n_dense_blocks * h < 0x7fffffffLL && h * d < 0x7fffffffLL;
 }
 inline BlockView block_view(const graphop_plan* plan) {
@@ -1237,7 +1249,8 @@ std::vector<TuneEntry> tune_table() {
       {"spmm_flat_cpg", &t.spmm_flat_cpg}, {"spmm_flat_max_mean", &t.spmm_flat_max_mean},
       {"spmm_flat_min_chunks", &t.spmm_flat_min_chunks}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
-      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps}};
+      {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps},
+      {"plan_trim", &t.plan_trim}};
 }
 }  // namespace
 
@@ -1452,13 +1465,23 @@ int graphop_plan_array(const graphop_plan_t* plan, const char* name, int sweep, 
   *ptr = nullptr; *bytes = 0;
   const graphop_plan_info_t& in = plan->info;
   auto give = [&](const void* p, size_t n) { if (p) { *ptr = p; *bytes = (int64_t)n; } return GRAPHOP_OK; };
+  // (export is a setup path: arrays the plan dropped after building its layouts -- plan.hip: plan_trim -- are rebuilt
+  // here on the default stream, so a container always holds the full derived state)
   if (sweep >= 0) {
     const Sweep* s = plan_sweep_at(plan, sweep);
     GO_CHECK_ARG(s != nullptr, "plan_array: no window structure %d", sweep);
+    if (!s->wp_lo || !s->wp_hi || !s->vr_row) {
+      const int rcw = plan_rebuild_sweep_tables(const_cast<graphop_plan*>(plan), s, nullptr);
+      if (rcw != GRAPHOP_OK) return rcw;
+    }
     if (!strcmp(name, "vr_row")) return give(s->vr_row, sizeof(int) * (size_t)s->V);
     if (!strcmp(name, "wp_lo")) return give(s->wp_lo, sizeof(int) * (size_t)s->V * s->W);
     if (!strcmp(name, "wp_hi")) return give(s->wp_hi, sizeof(int) * (size_t)s->V * s->W);
   } else {
+    if (!strcmp(name, "idx32") || !strcmp(name, "eid32")) {
+      const int rcm = plan_ensure_mirrors_locked(const_cast<graphop_plan*>(plan), nullptr);
+      if (rcm != GRAPHOP_OK) return rcm;
+    }
     if (!strcmp(name, "seg_chunk")) return give(plan->seg_chunk, sizeof(int64_t) * (size_t)(in.n_segments + 1));
     if (!strcmp(name, "idx32")) return give(plan->idx32, sizeof(int32_t) * (size_t)in.n_edges);
     if (!strcmp(name, "eid32")) return give(plan->eid32, sizeof(int32_t) * (size_t)in.n_edges);
@@ -1517,7 +1540,7 @@ int graphop_plan_sweep_dealt(const graphop_plan_t* plan, int sweep, int i, int32
 int graphop_plan_sweep_build_dealt(graphop_plan_t* plan, const graphop_sweep_info_t* info, int32_t L,
                                    int32_t K, void* stream) {
   GO_CHECK_ARG(plan && info, "plan_sweep_build_dealt: NULL pointer");
-  GO_CHECK_ARG(plan->idx32 != nullptr, "plan_sweep_build_dealt: the plan has no 32-bit mirrors");
+  GO_CHECK_ARG(plan->info.has_idx32, "plan_sweep_build_dealt: the plan has no 32-bit mirrors");
   for (int i = 0; i < plan_n_sweeps(plan); ++i) {
     const Sweep* s = plan_sweep_at(plan, i);
     if (s->W == info->W && s->win_cols == info->win_cols && s->T == info->T) {

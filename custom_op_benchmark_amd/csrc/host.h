@@ -63,6 +63,8 @@ struct Tuning {
   int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
   int walk_fault;         // tests only: inject a hand-over fault into the walk kernel (kernels_walk.h: WalkView::fault)
   int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
+  int plan_trim;          // 1: plans drop what only their layout builders read (32-bit mirrors, window tables) once an op has what
+                          // it launches with; rebuilt on demand (plan.hip: plan_trim)
   int n_cu;
   Tuning() {
     sweep = env_int("GRAPHOP_SWEEP", 1);
@@ -104,6 +106,7 @@ struct Tuning {
     walk_blocks = env_int("GRAPHOP_WALK_BLOCKS", 0);
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);
     walk_fault = 0;
+    plan_trim = env_int("GRAPHOP_PLAN_TRIM", 1);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -147,6 +150,7 @@ struct SweepOpts {
   int touch = 0;          // SweepView::touch of the launch
   int staged = 0;         // 1: also fetch / build the dealt (window-major) layout and put it in the view
   int stage_lds_per_group = 0;   // bytes of LDS each lane group needs for staging (added to lds_bytes)
+  int no_eids = 0;        // 1: the kernels never read edge ids (fused attention passes): the dealt layout keeps no copy of them
 };
 
 // Decide whether the window-sweep driver applies and fetch / build its structure.
@@ -162,6 +166,12 @@ int plan_import_arrays(graphop_plan* p, const i64* seg_chunk, const int32_t* idx
 int plan_import_sweep(graphop_plan* p, int W, i64 win_cols, int T, int V, const int32_t* vr_row,
                       const int32_t* wp_lo, const int32_t* wp_hi, hipStream_t st);
 void plan_init_sweeps(graphop_plan*);
+int plan_ensure_mirrors(graphop_plan* p, hipStream_t st);
+int plan_pin_mirrors(graphop_plan* p, hipStream_t st);
+int plan_ensure_mirrors_locked(graphop_plan* p, hipStream_t st);
+int plan_rebuild_sweep_tables(graphop_plan* p, const Sweep* sw, hipStream_t st);
+int plan_pin_sweep_tables(graphop_plan* p, const Sweep* sw, hipStream_t st);
+void plan_trim(graphop_plan* p);
 // the fused attention passes' window structure for ONE orientation (attention.hip); dry run
 int attn_prepare_plan(const graphop_plan* plan, i64 n_table_rows, i64 d, bool col, hipStream_t st);
 

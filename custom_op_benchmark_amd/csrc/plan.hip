@@ -728,6 +728,132 @@ int plan_build_seg_eptr(graphop_plan* p, hipStream_t st) {
   return GRAPHOP_OK;
 }
 
+// ---- plan memory: what only the BUILDERS read is rebuilt on demand (round 5) ------------------------------
+// The 32-bit mirrors of the slot arrays (4-8 B per slot) and a window structure's wp_lo / wp_hi tables are inputs of the
+// layout builders; at run time only the per-batch ("non-staged") window-owner kernels and the block-dense kernels read
+// them -- the staged strips and the walk kernels read their own window-major copies.  On the Reddit shape that is
+// 1.6 of 5.7 GB of plan memory that no kernel of either step form touches.  They are therefore (re)built when a
+// builder or such a kernel needs them (from the caller's int64 arrays, which a plan may rely on: include/graphop_hip.h)
+// and dropped again by plan_trim unless a run-time reader has PINNED them (sticky flags: launches on other streams may
+// be reading).  Rebuilding allocates and synchronises like any other plan construction: not during a stream capture.
+int plan_ensure_mirrors(graphop_plan* p, hipStream_t st) {
+  if (!p->info.has_idx32) return GRAPHOP_OK;
+  const i64 E = p->info.n_edges;
+  const bool need_idx = p->indices && !p->idx32, need_eid = !p->info.eid_identity && p->eid && !p->eid32;
+  if (!need_idx && !need_eid) return GRAPHOP_OK;
+  const int rc_cap = check_not_capturing(st, "rebuilding the 32-bit index mirrors of a plan");
+  if (rc_cap != GRAPHOP_OK) return rc_cap;
+  if (need_idx) {
+    GO_HIP(go_malloc((void**)&p->idx32, sizeof(int32_t) * (size_t)E, st));
+    hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, (const i64*)p->indices, p->idx32, E);
+    GO_LAUNCH_CHECK();
+  }
+  if (need_eid) {
+    GO_HIP(go_malloc((void**)&p->eid32, sizeof(int32_t) * (size_t)E, st));
+    hipLaunchKernelGGL(k_narrow, dim3(grid_for(E, kBlock, 8192)), dim3(kBlock), 0, st, (const i64*)p->eid, p->eid32, E);
+    GO_LAUNCH_CHECK();
+  }
+  GO_HIP(hipStreamSynchronize(st));
+  return GRAPHOP_OK;
+}
+
+// (Re)build vr_row / wp_lo / wp_hi of a window structure; the first build also determines V.  Caller holds sweep_mu.
+static int sweep_fill_arrays(graphop_plan* p, Sweep& s, hipStream_t st) {
+  const i64 S = p->info.n_segments, E = p->info.n_edges;
+  const int W = s.W, T = s.T;
+  int rc = plan_ensure_mirrors(p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E < 0x7fffffffLL && S > 0,
+               "plan_get_sweep: plan is not sweepable");
+  const i64* indptr = (const i64*)p->indptr;
+  DevBuf seg_eptr, first, vr_seg, vr_ptr;
+  GO_HIP(go_malloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1), st));
+  GO_HIP(go_malloc(&first.p, sizeof(i64) * (size_t)(S + 1), st));
+  hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
+                     (const i64*)p->seg_chunk, indptr, S, (i64*)seg_eptr.p);
+  GO_LAUNCH_CHECK();
+  rc = partition_count((const i64*)seg_eptr.p, S, T, (i64*)first.p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  i64 V = 0;
+  GO_HIP(hipMemcpyAsync(&V, (i64*)first.p + S, sizeof(i64), hipMemcpyDeviceToHost, st));
+  GO_HIP(hipStreamSynchronize(st));
+  GO_CHECK_ARG(V > 0 && V < 0x7fffffffLL && V * (W + 1) < (i64)1 << 40, "plan_get_sweep: size");
+  GO_CHECK_ARG(s.V == 0 || s.V == (int)V, "plan_get_sweep: the graph changed under its plan");
+  GO_HIP(go_malloc(&vr_seg.p, sizeof(i64) * (size_t)V, st));
+  GO_HIP(go_malloc(&vr_ptr.p, sizeof(i64) * (size_t)(V + 1), st));
+  rc = partition_fill((const i64*)seg_eptr.p, (const i64*)first.p, S, T, V, (i64*)vr_seg.p,
+                      (i64*)vr_ptr.p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  DevBuf rw;
+  GO_HIP(go_malloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1)), st));
+  hipLaunchKernelGGL(k_sweep_row_windows, dim3(grid_for(S * (W + 1), kBlock, 16384)), dim3(kBlock),
+                     0, st, (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, s.win_cols,
+                     (int*)rw.p);
+  GO_LAUNCH_CHECK();
+  s.V = (int)V;
+  const size_t wp_bytes = sizeof(int) * (size_t)(V * W);
+  if ((!s.vr_row && go_malloc((void**)&s.vr_row, sizeof(int) * (size_t)V, st) != hipSuccess) ||
+      (!s.wp_lo && go_malloc((void**)&s.wp_lo, wp_bytes, st) != hipSuccess) ||
+      (!s.wp_hi && go_malloc((void**)&s.wp_hi, wp_bytes, st) != hipSuccess)) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
+    s.vr_row = s.wp_lo = s.wp_hi = nullptr;
+    set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
+    return GRAPHOP_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_sweep_fill, dim3(grid_for(V * W, kBlock, 16384)), dim3(kBlock), 0, st,
+                     (const i64*)vr_seg.p, (const i64*)first.p, (const i64*)p->seg_chunk,
+                     (const i64*)p->row, (const int*)rw.p, S, V, W, s.vr_row, s.wp_lo, s.wp_hi);
+  GO_LAUNCH_CHECK();
+  GO_HIP(hipStreamSynchronize(st));
+  return GRAPHOP_OK;
+}
+
+// A launch is about to READ a window structure's tables and the mirrors at run time (per-batch window-owner kernels):
+// make them resident and keep them (sticky).  staged launches do not call this.
+int plan_pin_sweep_tables(graphop_plan* p, const Sweep* sw, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  Sweep* s = const_cast<Sweep*>(sw);
+  p->mirrors_pinned = 1;
+  s->runtime_wp = 1;
+  int rc = plan_ensure_mirrors(p, st);
+  if (rc != GRAPHOP_OK) return rc;
+  if (!s->wp_lo || !s->wp_hi || !s->vr_row) {
+    const int rc_cap = check_not_capturing(st, "rebuilding the window tables of a plan");
+    if (rc_cap != GRAPHOP_OK) return rc_cap;
+    rc = sweep_fill_arrays(p, *s, st);
+  }
+  return rc;
+}
+// (export path) rebuild without pinning; take the plan's mutex
+int plan_rebuild_sweep_tables(graphop_plan* p, const Sweep* sw, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  return sweep_fill_arrays(p, *const_cast<Sweep*>(sw), st);
+}
+int plan_ensure_mirrors_locked(graphop_plan* p, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  return plan_ensure_mirrors(p, st);
+}
+int plan_pin_mirrors(graphop_plan* p, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  p->mirrors_pinned = 1;
+  return plan_ensure_mirrors(p, st);
+}
+
+// Drop what only builders read (see above).  Called when an op has everything it needs for its launch.
+void plan_trim(graphop_plan* p) {
+  if (!tuning_plan_trim()) return;
+  std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
+  if (!p->mirrors_pinned && p->info.has_idx32 && !p->blk_seg) {
+    if (p->idx32 && p->indices) { go_free(p->idx32); p->idx32 = nullptr; }
+    if (p->eid32 && p->eid) { go_free(p->eid32); p->eid32 = nullptr; }
+  }
+  for (auto& s : *(std::vector<Sweep>*)p->sweeps)
+    if (!s.runtime_wp && s.n_dealt > 0) {
+      go_free(s.wp_lo); go_free(s.wp_hi);
+      s.wp_lo = s.wp_hi = nullptr;
+    }
+}
+
 // Build (or fetch) the window-sweep structure for W windows of win_cols ids and vrows of <= T slots.
 int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, const Sweep** out) {
   auto* mu = (std::mutex*)p->sweep_mu;
@@ -753,50 +879,17 @@ int plan_get_sweep(graphop_plan* p, int W, i64 win_cols, int T, hipStream_t st, 
     const int rc_cap = check_not_capturing(st, "building the column-window structure of a plan");
     if (rc_cap != GRAPHOP_OK) return rc_cap;
   }
-  const i64 S = p->info.n_segments, E = p->info.n_edges;
-  GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E < 0x7fffffffLL && S > 0,
-               "plan_get_sweep: plan is not sweepable");
-  const i64* indptr = (const i64*)p->indptr;
-  DevBuf seg_eptr, first, vr_seg, vr_ptr;
-  GO_HIP(go_malloc(&seg_eptr.p, sizeof(i64) * (size_t)(S + 1), st));
-  GO_HIP(go_malloc(&first.p, sizeof(i64) * (size_t)(S + 1), st));
-  hipLaunchKernelGGL(k_seg_eptr, dim3(grid_for(S + 1, kBlock, 4096)), dim3(kBlock), 0, st,
-                     (const i64*)p->seg_chunk, indptr, S, (i64*)seg_eptr.p);
-  GO_LAUNCH_CHECK();
-  int rc = partition_count((const i64*)seg_eptr.p, S, T, (i64*)first.p, st);
-  if (rc != GRAPHOP_OK) return rc;
-  i64 V = 0;
-  GO_HIP(hipMemcpyAsync(&V, (i64*)first.p + S, sizeof(i64), hipMemcpyDeviceToHost, st));
-  GO_HIP(hipStreamSynchronize(st));
-  GO_CHECK_ARG(V > 0 && V < 0x7fffffffLL && V * (W + 1) < (i64)1 << 40, "plan_get_sweep: size");
-  GO_HIP(go_malloc(&vr_seg.p, sizeof(i64) * (size_t)V, st));
-  GO_HIP(go_malloc(&vr_ptr.p, sizeof(i64) * (size_t)(V + 1), st));
-  rc = partition_fill((const i64*)seg_eptr.p, (const i64*)first.p, S, T, V, (i64*)vr_seg.p,
-                      (i64*)vr_ptr.p, st);
-  if (rc != GRAPHOP_OK) return rc;
-  DevBuf rw;
-  GO_HIP(go_malloc(&rw.p, sizeof(int) * (size_t)(S * (W + 1)), st));
-  hipLaunchKernelGGL(k_sweep_row_windows, dim3(grid_for(S * (W + 1), kBlock, 16384)), dim3(kBlock),
-                     0, st, (const i64*)seg_eptr.p, (const int32_t*)p->idx32, S, W, win_cols,
-                     (int*)rw.p);
-  GO_LAUNCH_CHECK();
   Sweep s;
-  s.W = W; s.win_cols = win_cols; s.T = T; s.V = (int)V;
-  const size_t wp_bytes = sizeof(int) * (size_t)(V * W);
-  if (go_malloc((void**)&s.vr_row, sizeof(int) * (size_t)V, st) != hipSuccess ||
-      go_malloc((void**)&s.wp_lo, wp_bytes, st) != hipSuccess ||
-      go_malloc((void**)&s.wp_hi, wp_bytes, st) != hipSuccess ||
-      go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
-    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi);
-    go_free(s.queues);
-    set_error("plan_get_sweep: out of device memory for %lld window pointers", (long long)(2 * V * W));
+  s.W = W; s.win_cols = win_cols; s.T = T; s.V = 0;
+  if (go_malloc((void**)&s.queues, sizeof(int) * kQueueRing * kQueueInts, st) != hipSuccess) {
+    set_error("plan_get_sweep: out of device memory");
     return GRAPHOP_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_sweep_fill, dim3(grid_for(V * W, kBlock, 16384)), dim3(kBlock), 0, st,
-                     (const i64*)vr_seg.p, (const i64*)first.p, (const i64*)p->seg_chunk,
-                     (const i64*)p->row, (const int*)rw.p, S, V, W, s.vr_row, s.wp_lo, s.wp_hi);
-  GO_LAUNCH_CHECK();
-  GO_HIP(hipStreamSynchronize(st));
+  const int rc = sweep_fill_arrays(p, s, st);
+  if (rc != GRAPHOP_OK) {
+    go_free(s.vr_row); go_free(s.wp_lo); go_free(s.wp_hi); go_free(s.queues);
+    return rc;
+  }
   vec->push_back(s);
   *out = &vec->back();
   return GRAPHOP_OK;
@@ -817,11 +910,14 @@ int* plan_take_queue(graphop_plan* p, const Sweep* sw) {
 }
 
 // The dealt layout of `sw` for groups of L lanes with K vrows each (built once, kept with the sweep).
-int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t st, const Sweep::Dealt** out) {
+int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t st, const Sweep::Dealt** out, bool want_eids) {
+  // want_eids = false: the consumer never reads edge ids (the fused attention passes recompute their per-edge scalars):
+  // no window-major copy of eid is kept for it (4 B per slot: 458 MB on the Reddit shape's column-major plan)
   std::lock_guard<std::mutex> lk(*(std::mutex*)p->sweep_mu);
   Sweep* s = const_cast<Sweep*>(sw);
+  const bool need_eids = want_eids && !p->info.eid_identity;
   for (int i = 0; i < s->n_dealt; ++i)
-    if (s->dealt[i].L == L && s->dealt[i].K == K) { *out = &s->dealt[i]; return GRAPHOP_OK; }
+    if (s->dealt[i].L == L && s->dealt[i].K == K && (!need_eids || s->dealt[i].eids != nullptr)) { *out = &s->dealt[i]; return GRAPHOP_OK; }
   *out = nullptr;
   if (s->n_dealt >= Sweep::kMaxDealt) return GRAPHOP_OK;   // caller falls back to the plain strips
   {
@@ -829,6 +925,11 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
     if (rc_cap != GRAPHOP_OK) return rc_cap;
   }
   GO_CHECK_ARG(L >= 1 && L <= 64 && (64 % L) == 0 && K >= 1 && K <= L, "plan_get_dealt: bad geometry");
+  {
+    int rc_in = plan_ensure_mirrors(p, st);                                            // (builder inputs: may have been trimmed)
+    if (rc_in == GRAPHOP_OK && (!s->wp_lo || !s->wp_hi || !s->vr_row)) rc_in = sweep_fill_arrays(p, *s, st);
+    if (rc_in != GRAPHOP_OK) return rc_in;
+  }
   const int GW = 64 / L, tile = GW * K;
   const i64 tiles = ceil_div((i64)s->V, tile);
   const i64 tasks = tiles * s->W, strips = tasks * GW;
@@ -839,7 +940,7 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
   d.n_ids = E + 3 * strips + 1024;   // upper bound: every strip padded to 4 ints; slack: a strip's last segment is fetched whole
   DevBuf len, tmp;
   GO_HIP(go_malloc(&len.p, sizeof(int) * (size_t)(strips + 1), st));
-  const bool with_eid = !p->info.eid_identity && p->eid32;
+  const bool with_eid = need_eids && p->eid32;
   if (go_malloc((void**)&d.rec, sizeof(int4) * (size_t)(tasks * tile), st) != hipSuccess ||
       go_malloc((void**)&d.ids, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess ||
       (with_eid && go_malloc((void**)&d.eids, sizeof(int) * (size_t)d.n_ids, st) != hipSuccess)) {
@@ -888,6 +989,10 @@ int plan_get_walk(graphop_plan* p, int W, i64 win_cols, int groups, int GW, int 
     if (rc_cap != GRAPHOP_OK) return rc_cap;
   }
   (void)device_error_word(true);   // the walk kernels report hand-over timeouts there; created here, outside any capture
+  {
+    const int rc_m = plan_ensure_mirrors(p, st);     // (builder input: may have been trimmed)
+    if (rc_m != GRAPHOP_OK) return rc_m;
+  }
   const i64 S = p->info.n_segments, E = p->info.n_edges;
   GO_CHECK_ARG(p->info.row_owned && p->sorted_in_rows && p->idx32 && E > 0 && E < 0x7fffffffLL && S > 0 &&
                W >= 1 && groups >= 1 && GW >= 1 && GW <= 4 && groups % GW == 0 && K >= 1 && K <= kWalkK,

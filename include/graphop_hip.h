@@ -110,7 +110,7 @@ GRAPHOP_API int graphop_check_device_errors(void);
  * flushed per window), walk_window_kb, walk_window_kb_col, walk_drift, walk_steps, walk_min_bin,
  * walk_blocks, walk_debug, walk_fault (tests: hand-over fault injection), spmm_selfzero, spmm_selfzero_min_mb
  * (row-owning chunk driver defines every output row itself: no zero fill of outputs of at least that many MB),
- * spmm_flat (0/1), spmm_flat_max_mean, spmm_flat_min_chunks, spmm_flat_cpg (that driver in its slot-walking form below
+ * plan_trim (0/1: plans drop builder inputs no kernel reads, see "device memory of plans"), spmm_flat (0/1), spmm_flat_max_mean, spmm_flat_min_chunks, spmm_flat_cpg (that driver in its slot-walking form below
  * that many slots per chunk on average, for chunk lists at least that long, with that many chunks per lane group).  Not thread-safe against
  * concurrent op calls; results never depend on them.  (Removed in ABI 6: sweep_mode, sweep_drift,
  * sweep_prefetch, transpose_scalars -- the paced vrow-owner sweep and the scalar transpose pre-pass,
@@ -127,9 +127,11 @@ GRAPHOP_API const char* graphop_tune_key(int i);
 GRAPHOP_API int64_t graphop_memory_bytes(void);
 
 /* ---- device memory of plans ------------------------------------------------------------------
- * Plans own device arrays (per orientation: 8 B per chunk, 4-8 B per edge of 32-bit mirrors, and
- * 8 B x windows x rows per window geometry in use, 4-8 B per edge per dealt / walk layout;
- * Reddit-shape: ~5.2 GB for both orientations once every pass of the step has run).
+ * Plans own device arrays (per orientation: 8 B per chunk and 4-8 B per edge per dealt / walk layout in use; the 32-bit
+ * mirrors of the slot arrays (4-8 B per edge) and a window structure's tables (8 B x windows x rows) are builder inputs:
+ * kept only while a per-batch window kernel reads them at run time, otherwise dropped once the layouts exist and
+ * rebuilt on demand -- knob plan_trim.  Reddit-shape, both orientations: 2.3 GB once the 8-function step has run,
+ * 3.8 GB with the fused op's layouts next to them; round 4: 5.7 GB).
  * By default they come from hipMalloc / hipFree (each a device-wide synchronisation).  A binding
  * may route them through its framework's allocator: alloc_fn(bytes, device, stream) returns a
  * device pointer usable on `stream` (NULL = out of memory), free_fn(ptr) releases it with

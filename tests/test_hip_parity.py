@@ -968,7 +968,7 @@ def test_seventeenth_window_geometry_is_counted_not_silent(dev, capfd):
             _lib.tune("sweep_w", w)
             s = ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, Q, K)
             want = s if want is None else want
-            torch.testing.assert_close(s, want, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(s, want, rtol=1e-4, atol=1e-5)      # (window strips and chunk driver sum in different orders)
         plan = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, 1200)
         assert plan.refresh_info().n_geometry_fallbacks >= 2        # W = 18 and W = 19 found the plan full
         assert "already holds 16 window geometries" in capfd.readouterr().err

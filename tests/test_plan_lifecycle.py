@@ -159,7 +159,7 @@ def test_container_carries_plan_state(dev, tmp_path, small_windows):
     q, k, v = (inp[x].to(dev).requires_grad_(True) for x in ("Q", "K", "V"))
     s, a, o = functions.attention_step(g2, q, k, v, inp["dO"][:g.n_src].to(dev))
     torch.cuda.synchronize()
-    assert _lib.plan_memory_bytes() == held           # nothing rebuilt
+    assert _lib.plan_memory_bytes() <= held           # nothing built (the plans may DROP imported builder inputs: plan_trim)
     for name, got, ref in (("s", s, want["s"]), ("a", a, want["a"]), ("o", o, want["o"]), ("dQ", q.grad, want["dQ"]),
                            ("dK", k.grad, want["dK"]), ("dV", v.grad, want["dV"])):
         torch.testing.assert_close(got.detach().cpu(), ref, rtol=1e-4, atol=1e-5, msg=lambda m: name + ": " + m)

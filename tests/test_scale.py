@@ -103,6 +103,8 @@ def test_reddit_scale_fused_equals_unfused(dev):
     lhs = (Q.double() * q.grad.double()).sum()
     torch.testing.assert_close((K.double() * k.grad.double()).sum(), lhs, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close((K.double() * k2.grad.double()).sum(), (Q.double() * q2.grad.double()).sum(), rtol=1e-5, atol=1e-6)
+    # plan memory of BOTH step forms together (round 5: builder inputs are dropped once the layouts exist; round 4: 5.66 GB)
+    assert _lib.plan_memory_bytes() <= 4.0 * 2**30, _lib.plan_memory_bytes() / 2**30
 
 
 @pytest.mark.parametrize("h,d", [(8, 32), (4, 16)])
