@@ -400,3 +400,76 @@ def test_fused_forward_walk_matches_composed_forward_medium(dev, force_fwd_walk)
     o0, st0 = ops.attention_forward(*a4, Q, K, V)
     torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(st1, st0, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["keep", "recompute"])
+@pytest.mark.parametrize("h,d", [(8, 32), (8, 16), (4, 64), (2, 128), (6, 16), (8, 64)])
+def test_fused_head_groups_vs_oracle(dev, force_sweep, h, d, mode, monkeypatch):
+    """Round 5: FusedAttention over several heads runs in head groups of 256-B rows (one head per group from d = 64 on,
+    where the one-head fused kernels apply to every head): no (E, h) tensor exists, the E-sized temporaries are (E, hg).
+    Both modes -- a_g kept per group / recomputed in the backward -- against the oracle, on a non-square graph, with the
+    window drivers forced so that the groups take the fused kernels where they apply (d <= 64, one head per group)."""
+    monkeypatch.setattr(functions, "FUSED_HEADS_MODE", mode)
+    hg = functions._head_group(h, d)
+    assert hg * d * 4 <= 256 or hg == 1
+    g = random_graph(700, 941, 14000, seed=3 + h + d, chunk_size=32, zero_rows=0.1, hub=900)
+    inp = rand_inputs(g, h, d, seed=5, normal=True)
+    dO = inp["dO"][:g.n_src]
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], torch.cat([dO, torch.zeros(g.n_dst - g.n_src, h, d)]))
+    gd = g.to(dev)
+    tags = prof_tags(lambda: fused_step(gd, inp["Q"].to(dev), inp["K"].to(dev), inp["V"].to(dev), dO.to(dev)))
+    if d == 64:
+        assert {"attn_bwd_row", "attn_bwd_col"} <= tags, tags        # every head through the fused one-head passes
+    got = fused_step(gd, inp["Q"].to(dev), inp["K"].to(dev), inp["V"].to(dev), dO.to(dev))
+    close(got["o"], want["o"][:g.n_src])
+    for k in ("dQ", "dK", "dV"):
+        close(got[k], want[k])
+
+
+def test_fused_head_groups_hold_no_e_by_h_tensor(dev):
+    """The memory deliverable of the head groups, at a size where it shows (E x h = 16 M floats = 64 MB per edge tensor):
+    the peak the fused step adds to what is allocated before it is well below the 8-function step's, in both modes."""
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    N, E, h, d = 20000, 2_000_000, 8, 32
+    g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=3, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    Q, K, V, dO = (torch.randn(N, h, d, device=dev, generator=gen) / 8 for _ in range(4))
+
+    def peak(step):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
+        step()
+        torch.cuda.synchronize()
+        return torch.cuda.max_memory_allocated() - base
+
+    def unfused():
+        q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        a8 = g.csr_args()
+        o = functions.VectorSPMM.apply(*a8, functions.SparseSoftmax.apply(g.row, g.ptr_r, g.eid_r,
+                                                                         functions.MaskedMMCSR.apply(*a8, q, k)), v)
+        o.backward(dO)
+        return q.grad, k.grad, v.grad
+
+    def fused():
+        q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        functions.FusedAttention.apply(*g.csr_args(), q, k, v).backward(dO)
+        return q.grad, k.grad, v.grad
+
+    edge_tensor = E * h * 4
+    p_unfused = peak(unfused)
+    ref = unfused()
+    results = {}
+    for mode in ("keep", "recompute"):
+        functions.FUSED_HEADS_MODE = mode
+        try:
+            results[mode] = peak(fused)
+            for a, b in zip(fused(), ref):
+                torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
+        finally:
+            functions.FUSED_HEADS_MODE = "keep"
+    assert p_unfused >= 2.9 * edge_tensor                       # a, da, ds (and s while the softmax runs)
+    assert results["keep"] <= 0.62 * p_unfused, (results, p_unfused)        # a in groups + one group's da, ds
+    assert results["recompute"] <= 0.45 * p_unfused, (results, p_unfused)   # one group's s / a / da / ds
