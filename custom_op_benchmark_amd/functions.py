@@ -84,15 +84,21 @@ class VectorSPMM(Function):
 FUSED_HEADS_MODE = "keep"
 
 
-def _head_group(h, d):
+def _head_group(h, d, n_edges=None, n_nodes=None):
     """Heads per group of the head-blocked FusedAttention: rows of hg x d floats = 256 B where d allows (the row width
     every driver is fastest at per byte: Reddit-shape 2 x 32 runs 13.6 ms against 55.4 / 4 at 8 x 32), one head per
-    group from d = 64 on (d = 64: the one-head fused kernels then apply to every head).  hg divides h; hg == h: no blocking."""
+    group from d = 64 on (d = 64: the one-head fused kernels then apply to every head).  hg divides h; hg == h: no blocking.
+    With the graph's size given, blocking is only chosen where it SAVES memory: it trades (E, h)-sized temporaries
+    (2 E (h - hg) floats) for about seven node-sized copies per group (7 n hg d floats) -- on graphs of few edges per
+    node the node tensors are the big ones (products-shape 8 x 16, E / n = 25: measured 1.5 x the 8-function step's peak
+    and +18 % time with groups of 4, tools/fused_heads_memory.py), so the margin is a factor two."""
     want = max(1, 64 // max(1, d))
     hg = 1
     for c in range(1, h + 1):
         if h % c == 0 and c <= want:
             hg = c
+    if n_edges is not None and n_nodes and hg < h and 2 * n_edges * (h - hg) < 2 * 7 * n_nodes * hg * d:
+        return h
     return hg
 
 
@@ -111,7 +117,7 @@ class FusedAttention(Function):
     def forward(ctx, row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c, Q, K, V):
         a8 = (row, indptr_r, eid_r, indices_r, col, indptr_c, eid_c, indices_c)
         h = Q.size(1) if Q.dim() == 3 else 1
-        hg = _head_group(h, Q.size(-1)) if h > 1 else 1
+        hg = _head_group(h, Q.size(-1), eid_r.numel(), max(Q.size(0), K.size(0))) if h > 1 else 1
         ctx.groups = None
         if h > 1 and hg < h:
             import os

@@ -430,7 +430,9 @@ def test_fused_head_groups_hold_no_e_by_h_tensor(dev):
     """The memory deliverable of the head groups, at a size where it shows (E x h = 16 M floats = 64 MB per edge tensor):
     the peak the fused step adds to what is allocated before it is well below the 8-function step's, in both modes."""
     _lib.tune_reset(); _lib.clear_plan_cache()
-    N, E, h, d = 20000, 2_000_000, 8, 32
+    N, E, h, d = 20000, 8_000_000, 8, 32
+    assert functions._head_group(8, 16, 61_859_140, 2_449_029) == 8       # products-shape: node tensors dominate, no blocking
+    assert functions._head_group(h, d, E, N) == 2
     g = graphs.chung_lu_graph(N, E, alpha=0.5, seed=3, device=dev)
     gen = torch.Generator(device=dev).manual_seed(5)
     Q, K, V, dO = (torch.randn(N, h, d, device=dev, generator=gen) / 8 for _ in range(4))
@@ -471,5 +473,5 @@ def test_fused_head_groups_hold_no_e_by_h_tensor(dev):
         finally:
             functions.FUSED_HEADS_MODE = "keep"
     assert p_unfused >= 2.9 * edge_tensor                       # a, da, ds (and s while the softmax runs)
-    assert results["keep"] <= 0.62 * p_unfused, (results, p_unfused)        # a in groups + one group's da, ds
-    assert results["recompute"] <= 0.45 * p_unfused, (results, p_unfused)   # one group's s / a / da / ds
+    assert results["keep"] <= 0.70 * p_unfused, (results, p_unfused)        # a in groups + one group's da, ds (Reddit shape: 0.59)
+    assert results["recompute"] <= 0.50 * p_unfused, (results, p_unfused)   # one group's s / a / da / ds (Reddit shape: 0.35)
