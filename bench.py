@@ -180,6 +180,9 @@ def main():
                          "process group, all_to_all_single with async handles and split-size views, no world == 1 short-cut -- "
                          "with the destinations drawn from the global distribution (--cut) fetched through the exchange as a "
                          "self-halo; use with --graph papers100m / rmat25")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="sharded steps: keep the default schedule (K and V exchanged separately, column-major backward passes "
+                         "split) instead of measuring the schedules the shard supports and adopting the fastest (dist.autotune)")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the step once into a HIP graph and time its replays (single GPU; for the "
                          "launch-bound small shapes -- the headline line is measured with eager API calls)")
@@ -319,6 +322,12 @@ def main():
     log("graph %s N=%d E=%d C=%d C'=%d built in %.1f s; first step (plans) %.2f s" %
         (name, n_rows, g.n_edges, g.n_row_chunks, g.n_col_chunks, t_graph, t_first))
 
+    # sharded steps: measure the schedules the shard supports (K | V packed or not, column-major backward passes fused or
+    # not) on THIS machine and adopt the fastest -- which one wins depends on the links (dist.ShardedAttention.autotune)
+    schedule = None
+    if runner is not None and not args.no_autotune:
+        schedule = runner.autotune(Q, K, V, dO, steps=2)
+        log("schedules (ms per step, max over ranks): %s -> kv_packed=%s columns_fused=%s" % (schedule, runner.pack_kv, runner.fuse_columns))
     for _ in range(args.warmup):
         step()
 
@@ -510,6 +519,16 @@ def main():
         fam = "k_spmm_*" if kname.startswith("k_spmm") else ("k_sddmm_*" if kname.startswith("k_sddmm") else kname)
         k = kern.setdefault(fam, {"ms": 0.0, "bytes": 0.0, "launches": 0, "names": set()})
         k["ms"] += ms; k["bytes"] += pb[tag]; k["launches"] += 1; k["names"].add(kname)
+    if "spmm_pair_cols" in prof:
+        # sharded step with the column-major backward passes fused (graphop_spmm_pair): dV and dK in one launch
+        pp = prof.pop("spmm_pair_cols")
+        ms = pp["mean_ms"]
+        b = pb["spmm_bwd_dx"] + pb["sddmm_bwd_dB"] - g.n_edges * 16 - 16 * g.n_col_chunks    # ids, edge ids and chunk metadata read once
+        passes["spmm_bwd_dx+sddmm_bwd_dB"] = {"ms": round(ms, 4), "kernel": pp["kernel"], "alg_GB": round(b / 1e9, 4),
+                                              "alg_GBps": round(b / 1e6 / ms, 1), "elided_GB": 0.0,
+                                              "frac": round(b / 1e6 / ms / HBM_PEAK_GBS, 4), "moved_GB": None, "moved_frac": None}
+        k = kern.setdefault("k_spmm_*", {"ms": 0.0, "bytes": 0.0, "launches": 0, "names": set()})
+        k["ms"] += ms; k["bytes"] += b; k["launches"] += 1; k["names"].add(pp["kernel"])
     other = {t: {"ms_per_step": round(v["total_ms"] / nprof, 4), "launches_per_step": v["calls"] // nprof,
                  "kernel": v["kernel"]} for t, v in prof.items() if t not in PASS_TAGS}
     dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else ("none", {"ms": 1.0, "bytes": 0.0, "launches": 1, "names": set()})
@@ -558,7 +577,7 @@ def main():
                                 "frac_of_bound": round(l1_ms / ms_per_step, 4)}
     if table_bytes > (512 << 20) and gather_drivers:
         gbytes = 6.0 * g.n_edges * h * d * 4
-        gms = sum(passes[t]["ms"] for t in GATHER_TAGS if t in passes)
+        gms = sum(pp_["ms"] for t, pp_ in passes.items() if not t.startswith("softmax"))
         roofline["gather_roofline"] = {
             "what": "secondary: 6 gather passes x E x F x 4 B of neighbour rows at the measured HBM random-row rate "
                     "(MI355X_MICROARCH.md, Indexed rows, HBM: 6.0-6.1 TB/s); the tables (%.1f GB each) are beyond the Infinity Cache"
@@ -573,7 +592,7 @@ def main():
         gbytes = 6.0 * g.n_edges * h * d * 4
         soft_bytes = sum(pb[t] for t in PASS_TAGS if t.startswith("softmax"))
         ceil_ms = gbytes / 1e6 / L2_GATHER_GBS + soft_bytes / 1e6 / HBM_PEAK_GBS
-        gms = sum(passes[t]["ms"] for t in GATHER_TAGS if t in passes)
+        gms = sum(pp_["ms"] for t, pp_ in passes.items() if not t.startswith("softmax"))
         roofline["l2_gather_ceiling"] = {
             "what": "secondary: the reachable ceiling of this operator surface on a cache-resident table: 6 gather passes x "
                     "E x F x 4 B of neighbour rows at the measured L2-resident lane-group gather rate (30 TB/s: "
@@ -623,6 +642,10 @@ def main():
                                     "N > 1 values among themselves and with `bench.py --gpus 1 --graph %s` (the same shard "
                                     "without halo)" % ("4" if name == "papers100m" else "5" if name == "rmat25" else "?", name, name))
         cfg["halo"] = runner.halo_stats(h * d * 4)
+        cfg["schedule"] = {"kv_packed": bool(cfg["halo"]["kv_packed"]), "columns_fused": bool(runner.fuse_columns),
+                           "measured_ms_per_step": schedule,
+                           "how": ("dist.ShardedAttention.autotune: every schedule timed for 2 steps after a warm-up, max over "
+                                   "ranks, fastest adopted by all ranks" if schedule else "default (--no-autotune)")}
         # per-exchange wall times, measured in a separate pass (their syncs defeat the overlap)
         runner.timers = {}
         for _ in range(2):

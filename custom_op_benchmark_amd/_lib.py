@@ -76,6 +76,8 @@ _SIGNATURES = {
     "graphop_sparse_softmax_backward": [ctypes.c_int] + [_P] * 6 + [_c64] * 3 + [_P, _c64, _P, _P],
     "graphop_vector_spmm_forward": [ctypes.c_int] + [_P] * 7 + [_c64] * 6 + [_P, _P],
     "graphop_vector_spmm_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
+    "graphop_spmm_pair_supported": [ctypes.c_int] + [_c64] * 5 + [_P],
+    "graphop_spmm_pair": [ctypes.c_int] + [_P] * 9 + [_c64] * 6 + [_P, _P],
     "graphop_node_mul_edge_forward": [ctypes.c_int] + [_P] * 6 + [_c64] * 5 + [_P, _P],
     "graphop_node_mul_edge_backward": [ctypes.c_int] + [_P] * 8 + [_c64] * 5 + [_P, _P],
     "graphop_gather_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],

@@ -1761,7 +1761,9 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     if (!covered) GO_HIP(zero_async(dedata, es * (size_t)(n_edges * h), st));
   }
   bool sz_x = false;
-  if (n_x * h * d > 0) {
+  // (dx may be NULL when n_col_chunks == 0: that half of the op is skipped, as in maskedmm_csr_backward -- the sharded
+  // step computes dx together with dK in one column-major launch, graphop_spmm_pair)
+  if (n_x * h * d > 0 && !(dx == nullptr && n_col_chunks == 0)) {
     GO_PTR(fn, dx);
     sz_x = edata != nullptr && dy != nullptr &&
            spmm_selfzero(dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t, (const i64*)indices_t, n_col_chunks,
@@ -1783,6 +1785,75 @@ int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* i
     GO_TRY(launch_spmm<false>("spmm_bwd_dx", dtype, (const i64*)col, (const i64*)indptr_t, (const i64*)eid_t,
                               (const i64*)indices_t, edata, dy, dx, n_col_chunks, n_edges, n_dy, h, d, plan_c, st, sz_x ? n_x : -1));
   }
+  return GRAPHOP_OK;
+}
+
+int graphop_spmm_pair_supported(int dtype, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t h, int64_t d,
+                                const graphop_plan_t* plan) {
+  if (tuning().force_generic || dtype != GRAPHOP_F32 || h != 1 || (d != 64 && d != 128 && d != 256)) return 0;
+  if (!plan || !plan->info.rows_sorted || plan->info.n_chunks != n_chunks || plan->info.n_edges != n_edges) return 0;
+  return n_edges < 0x7fffffffLL && n_x < 0x7fffffffLL && plan->info.max_index < n_x;
+}
+
+int graphop_spmm_pair(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                      const int64_t* indices, const void* w2, const void* X0, const void* X1, void* out0,
+                      void* out1, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t n_out, int64_t h,
+                      int64_t d, const graphop_plan_t* plan, void* stream) {
+  const char* fn = "spmm_pair";
+  GO_TRY(check_common(fn, dtype, n_chunks, n_edges, h, d));
+  hipStream_t st = (hipStream_t)stream;
+  GO_CHECK_ARG(plan_matches_full(plan, (const i64*)row, (const i64*)indptr, (const i64*)eid, (const i64*)indices, n_chunks, n_edges) &&
+               graphop_spmm_pair_supported(dtype, n_chunks, n_edges, n_x, h, d, plan) && aligned16(out0) && aligned16(out1),
+               "%s: not supported for these operands (fp32, one head, d in {64, 128, 256}, a plan of these arrays with sorted "
+               "rows, 16-byte-aligned outputs): run the two passes separately", fn);
+  GO_CHECK_ARG(n_out >= 0 && plan->info.max_row < n_out && n_out < 0x7fffffffLL, "%s: row id %lld but the outputs have %lld rows", fn,
+               (long long)plan->info.max_row, (long long)n_out);
+  const size_t row_b = sizeof(float) * (size_t)d;
+  if (n_out * d == 0) return GRAPHOP_OK;
+  GO_PTR(fn, out0); GO_PTR(fn, out1);
+  if (n_chunks == 0) {
+    GO_HIP(zero_async(out0, row_b * (size_t)n_out, st));
+    GO_HIP(zero_async(out1, row_b * (size_t)n_out, st));
+    return GRAPHOP_OK;
+  }
+  GO_PTR(fn, w2); GO_PTR(fn, X0); GO_PTR(fn, X1);
+  // self-zeroing as in launch_spmm: rows a lane group owns are stored, edge-less rows between chunk rows zero-stored by the
+  // group that sees the gap, the tail behind the last chunk row from here; not with gaps of more than 4 MB of rows
+  const bool sz = tuning().spmm_selfzero && (double)plan->info.max_row_gap * (double)d * 4.0 <= 4.0 * 1048576.0;
+  i64 covered = 0;
+  if (sz) {
+    covered = plan->info.max_row + 1;
+    if (covered < n_out) {
+      GO_HIP(zero_async((char*)out0 + row_b * (size_t)covered, row_b * (size_t)(n_out - covered), st));
+      GO_HIP(zero_async((char*)out1 + row_b * (size_t)covered, row_b * (size_t)(n_out - covered), st));
+    }
+  } else {
+    GO_HIP(zero_async(out0, row_b * (size_t)n_out, st));
+    GO_HIP(zero_async(out1, row_b * (size_t)n_out, st));
+  }
+  const int cpg = cpg_for(n_chunks, tuning().spmm_flat_cpg, (int)d);
+  ProfScope prof("spmm_pair_cols", st, "k_spmm_flat2_f32");
+  GO_DISPATCH_LNV((int)d, {
+    if constexpr (NV == 1 && L >= 16) {
+      const i64 groups = ceil_div(n_chunks, cpg);
+      const unsigned nb = blocks_for(groups, GroupCfg<L>::kGroupsPerBlock);
+      if (sz) {
+        if (groups > 1) {
+          const unsigned zb = blocks_for(groups - 1, kFastBlock / L);
+          hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(zb), dim3(kFastBlock), 0, st, (const i64*)row, (float*)out0, n_chunks, cpg);
+          hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(zb), dim3(kFastBlock), 0, st, (const i64*)row, (float*)out1, n_chunks, cpg);
+        }
+        hipLaunchKernelGGL((k_spmm_flat2_f32<L, true>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row, (const i64*)indptr,
+                           (const i64*)eid, (const i64*)indices, (const float2*)w2, (const float*)X0, (const float*)X1,
+                           (float*)out0, (float*)out1, n_chunks, cpg, covered);
+      } else {
+        hipLaunchKernelGGL((k_spmm_flat2_f32<L, false>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row, (const i64*)indptr,
+                           (const i64*)eid, (const i64*)indices, (const float2*)w2, (const float*)X0, (const float*)X1,
+                           (float*)out0, (float*)out1, n_chunks, cpg, (i64)0);
+      }
+    }
+  });
+  GO_LAUNCH_CHECK();
   return GRAPHOP_OK;
 }
 

@@ -192,6 +192,12 @@ class ShardedAttention:
         # SDDMM forward as an own-column half (runs under the K exchange) and a halo-column half (after it)
         self.split_forward = bool(split_forward) and os.environ.get("GRAPHOP_DIST_SPLIT_FORWARD", "1") != "0"
         self.pack_kv = {"0": False, "1": True}.get(os.environ.get("GRAPHOP_DIST_PACK_KV", ""), pack_kv)   # True / False / "auto"
+        # the two column-major passes of the backward (dV = SpMM(a, dO), dK = SpMM(ds, Q)) as ONE launch over the column CSR
+        # with the weights packed as (E, 2) pairs (graphop_spmm_pair): one 8-byte random read per slot instead of two
+        # 4-byte ones in two passes, ids / metadata streamed once.  Both gradient exchanges then start together behind it
+        # and share the dQ pass as cover (split form: dV travels under softmax-backward + the dK pass, dK under dQ), so
+        # which form is faster depends on the links: autotune() measures both.  HIP path, fp32, one head, d in {64,128,256}.
+        self.fuse_columns = os.environ.get("GRAPHOP_DIST_FUSE_COLUMNS", "0") == "1"
         self.noop_exchange = False        # bench.py: exchanges do nothing at all (timing only: what a step costs without them)
         self.collectives_last_step = 0
         self.device = torch.device(device)
@@ -468,6 +474,14 @@ class ShardedAttention:
             o = self._spmm_forward_own_rows(a, V_ext)           # C ABI: n_y = n_own rows, no zero fill of the halo part
         else:
             o = ops.vector_spmm_forward(*a4, a, V_ext)[:n_own]  # reference surface: y = zeros_like(x), rows >= n_own are 0
+        if self.fuse_columns and self._columns_fusable(Qd, a):
+            dQ, dK, dV = self._backward_fused_columns(Qd, K_ext, V_ext, a, dO.detach().contiguous())
+            for t, gr in ((Q, dQ), (K, dK), (V, dV)):
+                if t.requires_grad:
+                    t.grad = gr
+            from . import _lib
+            _lib.check_errors(sync=False)
+            return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
         # dy is only indexed by row ids (< n_own): no need to pad it to the extended row count
         da, dV_ext = ops.vector_spmm_backward(*a8, a, dO.detach().contiguous(), V_ext)
         # backward exchange: partial rows computed for halo columns go home and are added there;
@@ -513,6 +527,95 @@ class ShardedAttention:
             from . import _lib
             _lib.check_errors(sync=False)     # a device-side abort of a finished launch is raised before the gradients leave
         return dict(o=o, dQ=dQ, dK=dK, dV=dV, s=s, a=a)
+
+    def _columns_fusable(self, Q, a):
+        if self.ops is not None or not Q.is_cuda or Q.dim() != 2 or a.dim() != 1 or Q.dtype != torch.float32:
+            return False
+        from . import _lib
+        g = self.graph
+        plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, Q.size(0))
+        return bool(_lib.lib().graphop_spmm_pair_supported(_lib.F32, g.col.size(0), g.n_edges, Q.size(0), 1, Q.size(-1),
+                                                           plan_c.handle))
+
+    def _backward_fused_columns(self, Q, K_ext, V_ext, a, dO):
+        """Backward with ONE column-major launch: da (row-major SDDMM) -> ds (softmax backward) -> (dV | dK) over the
+        column CSR with packed (a, ds) weights -> both gradient exchanges -> dQ (row-major) under them."""
+        from . import _lib
+        g, n_own, L = self.graph, self.n_own, _lib.lib()
+        er, ep = self._empty_chunks()
+        d = Q.size(-1)
+        st = _lib.stream_of(Q)
+        with _lib.device_guard(Q.device):
+            plan_r = _lib.get_plan(g.row, g.ptr_r, g.eid_r, g.indices_r, V_ext.size(0))
+            plan_c = _lib.get_plan(g.col, g.ptr_c, g.eid_c, g.indices_c, Q.size(0))
+            da = torch.empty_like(a)
+            # row-major half of vector_spmm_backward only: da = SDDMM(dO, V_ext); no dx, no column chunks
+            _lib.check(L.graphop_vector_spmm_backward(
+                _lib.F32, _lib.ptr(g.row), _lib.ptr(g.ptr_r), _lib.ptr(g.eid_r), _lib.ptr(g.indices_r), _lib.ptr(er), _lib.ptr(ep),
+                _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(a), _lib.ptr(dO), _lib.ptr(V_ext), _lib.ptr(da), None,
+                g.row.size(0), 0, g.n_edges, V_ext.size(0), dO.size(0), 1, d, plan_r.handle, None, st))
+        ds = self._ops().sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
+        w2 = torch.stack((a, ds), dim=1)                       # (E, 2): a slot's two weights are one 8-byte read
+        del da
+        dV_ext, dK_ext = torch.empty_like(V_ext), torch.empty_like(K_ext)
+        with _lib.device_guard(Q.device):
+            _lib.check(L.graphop_spmm_pair(
+                _lib.F32, _lib.ptr(g.col), _lib.ptr(g.ptr_c), _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(w2), _lib.ptr(dO),
+                _lib.ptr(Q), _lib.ptr(dV_ext), _lib.ptr(dK_ext), g.col.size(0), g.n_edges, Q.size(0), K_ext.size(0), 1, d,
+                plan_c.handle, st))
+        del w2
+        dV, dK = dV_ext[:n_own], dK_ext[:n_own]
+        exchange = self.n_halo or self.world > 1 or self.force
+        if exchange:
+            wait_dv, recv_dv = self.scatter_halo_grad_start(dV, dV_ext[n_own:], async_op=True, role="dV")
+            wait_dk, recv_dk = self.scatter_halo_grad_start(dK, dK_ext[n_own:], async_op=True, role="dK")
+        dQ = self._sddmm_backward_half(Q, K_ext, ds, col_half=False)
+        if exchange:
+            wait_dv.wait()
+            self._add_home(dV, recv_dv)
+            wait_dk.wait()
+            self._add_home(dK, recv_dk)
+        return dQ, dK, dV
+
+    def autotune(self, Q, K, V, dO, steps=2, candidates=None):
+        """Measure, don't guess: the step under every schedule the shard supports -- K | V halo rows as one grouped
+        exchange or two, the column-major backward passes as one launch or two -- `steps` steps each after one warm-up,
+        wall time between barriers, MAX over ranks; the fastest is adopted by EVERY rank (the choice is made from the
+        reduced times, so all ranks agree).  Which one wins depends on the links: packing delays the halo half of the
+        SDDMM until V has arrived too, fusing the columns leaves both gradient exchanges only the dQ pass as cover.
+        -> {schedule: ms}."""
+        import time
+        cuda = self.device.type == "cuda"
+        real = self.world > 1 and self.local is None and not self.emulate
+        fus = [False] + ([True] if self._columns_fusable(Q.detach().contiguous(), torch.empty(0, device=self.device)) else [])
+        packs = [False, True] if (self.n_halo > 0 or self.force) else [False]
+        cands = candidates or [(p, f) for f in fus for p in packs]
+
+        def sync():
+            if real:
+                dist.barrier(group=self.group)
+            if cuda:
+                torch.cuda.synchronize(self.device)
+
+        times = {}
+        for pack, fuse in cands:
+            self.pack_kv, self.fuse_columns = pack, fuse
+            self.step(Q, K, V, dO)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(Q, K, V, dO)
+            sync()
+            times[(pack, fuse)] = (time.perf_counter() - t0) / steps
+        keys = sorted(times)
+        t = torch.tensor([times[k] for k in keys], dtype=torch.float64,
+                         device=self.device if (real and dist.get_backend(self.group) == "nccl") else "cpu")
+        if real:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        best = keys[int(torch.argmin(t))]
+        self.pack_kv, self.fuse_columns = best
+        return {"kv_%s+columns_%s" % ("packed" if k[0] else "separate", "fused" if k[1] else "split"): round(1e3 * float(v), 3)
+                for k, v in zip(keys, t.tolist())}
 
     def _sddmm_forward_halves(self, Q, K_ext, wait_k):
         """s = SDDMM(Q, K_ext) as two launches over disjoint slot sets that share s: own columns first (no halo row is
@@ -603,7 +706,8 @@ class ShardedAttention:
                 "bytes_per_exchange_in": self.n_halo * row_bytes,
                 "bytes_per_exchange_out": int(self.serve_rows.numel()) * row_bytes,
                 "exchanges_per_step": 4, "collectives_last_step": self.collectives_last_step,
-                "kv_packed": self._pack_kv_now(row_bytes), "forward_split": self.fwd_halves is not None}
+                "kv_packed": self._pack_kv_now(row_bytes), "forward_split": self.fwd_halves is not None,
+                "columns_fused": bool(self.fuse_columns)}
 
     # ---- builders --------------------------------------------------------------------------------
     @classmethod

@@ -318,7 +318,8 @@ GRAPHOP_API int graphop_vector_spmm_forward(int dtype, const int64_t* row, const
  * dedata[eid[j], k] = <dy[row[c], k, :], x[indices[j], k, :]>           (row-major CSR)
  * dx[col[c], k, :] += sum_j edata[eid_t[j], k] * dy[indices_t[j], k, :]  (column-major CSR)
  * Every column chunk is processed (the reference sizes that grid by the ROW chunk count,
- * graphop_kernel.cu:566,588 -- a latent bug when the counts differ). */
+ * graphop_kernel.cu:566,588 -- a latent bug when the counts differ).
+ * dx may be NULL when n_col_chunks == 0 (that half is skipped: the op can be run one orientation at a time). */
 GRAPHOP_API int graphop_vector_spmm_backward(int dtype, const int64_t* row, const int64_t* indptr,
                                  const int64_t* eid, const int64_t* indices, const int64_t* col,
                                  const int64_t* indptr_t, const int64_t* eid_t,
@@ -327,6 +328,22 @@ GRAPHOP_API int graphop_vector_spmm_backward(int dtype, const int64_t* row, cons
                                  int64_t n_col_chunks, int64_t n_edges, int64_t n_x, int64_t n_dy,
                                  int64_t h, int64_t d, const graphop_plan_t* plan_r,
                                  const graphop_plan_t* plan_c, void* stream);
+
+/* ---- two SpMM-type passes over ONE chunked CSR as one launch (ABI 7; not in the reference) ---------------
+ *   out0[row[c], :] += sum_j w2[eid[j], 0] * X0[indices[j], :]      out1[row[c], :] += sum_j w2[eid[j], 1] * X1[indices[j], :]
+ * -- the arithmetic of two vector_spmm_forward-type kernel launches (graphop_kernel.cu:118-130; in the backward of the
+ * composed step: dV = SpMM(a, dO) and dK = SpMM(ds, Q) over the column-major CSR, :151-163 and :100-112) that share
+ * their slot list.  w2 is (n_edges, 2): a slot's two weights are ONE 8-byte read, and ids / edge ids / chunk metadata
+ * are streamed once.  The sharded step uses it for its column-major side, whose per-slot weights are a random gather
+ * (custom_op_benchmark_amd/dist.py).  X0, X1: (n_x, d); out0, out1: (n_out, d), need not be initialised.
+ * Supported (graphop_spmm_pair_supported != 0): fp32, one head, d in {64, 128, 256}, a plan of these arrays with sorted
+ * rows, 16-byte-aligned outputs; otherwise GRAPHOP_ERR_INVALID_ARGUMENT -- run the two passes separately. */
+GRAPHOP_API int graphop_spmm_pair_supported(int dtype, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t h,
+                                int64_t d, const graphop_plan_t* plan);
+GRAPHOP_API int graphop_spmm_pair(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
+                      const int64_t* indices, const void* w2, const void* X0, const void* X1, void* out0,
+                      void* out1, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t n_out, int64_t h,
+                      int64_t d, const graphop_plan_t* plan, void* stream);
 
 /* ---- node_mul_edge_forward(row, indptr, eid, A, B) -> y -------------------------------------
  * replaces graphop.cpp:39-51 / graphop_kernel.cu:235-266 (kernel :19-34).

@@ -48,6 +48,16 @@ def _worker(rank, world, port, h, d, out_dir, pack_kv, split_forward):
         assert sum(sh.recv_counts) == sh.n_halo and sh.recv_counts[rank] == 0
         r = sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
         assert sh.collectives_last_step == (3 if pack_kv else 4)     # K | V as one grouped exchange, or K and V; dV; dK
+        if world == 3:
+            # autotune: both exchange schedules timed, max over ranks, every rank adopts the same one
+            times = sh.autotune(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi], steps=1)
+            assert set(times) == {"kv_separate+columns_split", "kv_packed+columns_split"}
+            picks = [None] * world
+            dist.all_gather_object(picks, (sh.pack_kv, sh.fuse_columns, sorted(times.items())))
+            assert all(p == picks[0] for p in picks), picks
+            r2 = sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
+            for k in ("o", "dQ", "dK", "dV"):
+                torch.testing.assert_close(r2[k], r[k], rtol=1e-5, atol=1e-6)
         torch.save({k: v for k, v in r.items()} | {"lo": lo, "hi": hi, "edge_mask": m, "key": key_local},
                    os.path.join(out_dir, "r%d.pt" % rank))
         dist.barrier()

@@ -246,3 +246,81 @@ def test_bench_line_through_the_rccl_path(dev):
     assert cfg["halo"]["exchange_ms_is_local_copy"] is False and set(cfg["halo"]["exchange_ms"]) == fwd | {"grad_dV", "grad_dK"}
     assert cfg["halo"]["forward_split"] is True and "exposed_exchange_ms" in line and line["exposed_exchange_ms"] is not None
     assert line["value"] > 0 and line["n_gpus"] == 1
+
+
+def test_spmm_pair_entry_vs_oracle(dev):
+    """graphop_spmm_pair (ABI 7): two SpMM-type passes over one column-major chunked CSR in one launch, weights as (E, 2)
+    pairs -- against two oracle SpMMs; outputs handed over full of NaNs (the launch defines every row); short columns,
+    a hub column cut between lane groups, a third of the columns without edges, an empty tail."""
+    import oracle as orc
+    _lib.tune_reset(); _lib.clear_plan_cache()
+    for d, cs, cpg in ((64, 1, 3), (128, 32, 32), (256, 2, 70), (128, 1, 5)):
+        _lib.tune("spmm_flat_cpg", cpg)
+        g = random_graph(900, 1400, 2600, seed=d + cs, chunk_size=cs, zero_rows=0.0, hub=700)
+        gen = torch.Generator().manual_seed(d)
+        X0, X1 = torch.randn(g.n_src, d, generator=gen), torch.randn(g.n_src, d, generator=gen)
+        w0, w1 = torch.rand(g.n_edges, generator=gen), torch.randn(g.n_edges, generator=gen)
+        n_out = g.n_dst + 37                                            # rows behind the last column: zero
+        pad = lambda X: torch.cat([X, torch.zeros(n_out - X.size(0), d)]) if X.size(0) < n_out else X
+        want0 = orc.vector_spmm_forward(g.col, g.ptr_c, g.eid_c, g.indices_c, w0, pad(X0))[:n_out]
+        want1 = orc.vector_spmm_forward(g.col, g.ptr_c, g.eid_c, g.indices_c, w1, pad(X1))[:n_out]
+        gd = g.to(dev)
+        w2 = torch.stack((w0, w1), dim=1).to(dev)
+        X0d, X1d = X0.to(dev), X1.to(dev)
+        out0 = torch.full((n_out, d), float("nan"), device=dev)
+        out1 = torch.full((n_out, d), float("nan"), device=dev)
+        with _lib.device_guard(dev):
+            pc = _lib.get_plan(gd.col, gd.ptr_c, gd.eid_c, gd.indices_c, g.n_src)
+            assert _lib.lib().graphop_spmm_pair_supported(_lib.F32, gd.col.size(0), g.n_edges, g.n_src, 1, d, pc.handle)
+            _lib.check(_lib.lib().graphop_spmm_pair(_lib.F32, _lib.ptr(gd.col), _lib.ptr(gd.ptr_c), _lib.ptr(gd.eid_c),
+                                                    _lib.ptr(gd.indices_c), _lib.ptr(w2), _lib.ptr(X0d), _lib.ptr(X1d),
+                                                    _lib.ptr(out0), _lib.ptr(out1), gd.col.size(0), g.n_edges, g.n_src, n_out,
+                                                    1, d, pc.handle, _lib.stream_of(out0)))
+        torch.cuda.synchronize()
+        assert not torch.isnan(out0).any() and not torch.isnan(out1).any()
+        torch.testing.assert_close(out0.cpu(), want0, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out1.cpu(), want1, rtol=1e-4, atol=1e-5)
+        _lib.clear_plan_cache()
+    _lib.tune_reset()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hip_step_fused_columns_and_autotune(dev, world):
+    """The sharded step with its two column-major backward passes as ONE launch (fuse_columns) and K | V as one grouped
+    exchange, all shards on one GPU against the oracle; autotune() adopts one of the schedules it measured."""
+    g = random_graph(500, 500, 16000, seed=23, chunk_size=8, zero_rows=0.1, hub=700)
+    inp = rand_inputs(g, 1, 128, seed=24, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+
+    def shard(rank, handle):
+        sh = ShardedAttention.from_global_coo(g.src.to(dev), g.dst.to(dev), g.n_src, rank, world, dev, chunk_size=8, group=handle,
+                                              pack_kv=True)
+        sh.fuse_columns = True
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        args = [inp[k][lo:hi].to(dev).contiguous() for k in ("Q", "K", "V", "dO")]
+        _lib.profile_enable(True)
+        r = sh.step(*args)
+        torch.cuda.synchronize()
+        ext_ids = torch.cat([torch.arange(lo, hi, device=dev), sh.halo_ids])
+        key = (sh.graph.src + lo) * g.n_dst + ext_ids[sh.graph.dst]
+        return dict(lo=lo, hi=hi, key=key.cpu(), n_halo=sh.n_halo, recv=sh.recv_counts, **{k: v.detach().cpu() for k, v in r.items()})
+
+    parts = run_local_shards(world, shard)
+    tags = set(_lib.profile_read())
+    _lib.profile_enable(False)
+    assert "spmm_pair_cols" in tags and "spmm_bwd_dx" not in tags and "sddmm_bwd_dB" not in tags, tags
+    _check(g, want, parts)
+
+    def tuned(rank, handle):
+        sh = ShardedAttention.from_global_coo(g.src.to(dev), g.dst.to(dev), g.n_src, rank, world, dev, chunk_size=8, group=handle)
+        lo, hi = sh.bounds[rank], sh.bounds[rank + 1]
+        args = [inp[k][lo:hi].to(dev).contiguous() for k in ("Q", "K", "V", "dO")]
+        times = sh.autotune(*args, steps=1)
+        assert len(times) == 4 and (sh.pack_kv, sh.fuse_columns) in [(p, f) for p in (False, True) for f in (False, True)]
+        r = sh.step(*args)
+        torch.cuda.synchronize()
+        ext_ids = torch.cat([torch.arange(lo, hi, device=dev), sh.halo_ids])
+        key = (sh.graph.src + lo) * g.n_dst + ext_ids[sh.graph.dst]
+        return dict(lo=lo, hi=hi, key=key.cpu(), n_halo=sh.n_halo, recv=sh.recv_counts, **{k: v.detach().cpu() for k, v in r.items()})
+
+    _check(g, want, run_local_shards(world, tuned))
