@@ -555,8 +555,11 @@ class ShardedAttention:
                 _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(a), _lib.ptr(dO), _lib.ptr(V_ext), _lib.ptr(da), None,
                 g.row.size(0), 0, g.n_edges, V_ext.size(0), dO.size(0), 1, d, plan_r.handle, None, st))
         ds = self._ops().sparse_softmax_backward(g.row, g.ptr_r, g.eid_r, a, da)
-        w2 = torch.stack((a, ds), dim=1)                       # (E, 2): a slot's two weights are one 8-byte read
         del da
+        # (a, ds) as (E, 2) pairs: a slot's two weights are ONE 8-byte random read in the column pass (scattering them into
+        # the column CSR's slot order first so that they stream was built and measured: the 200 M scattered 8-byte stores
+        # cost 8.3 ms for a 5 ms faster pass -- profiles/r5_pair_columns_experiment.txt)
+        w2 = torch.stack((a, ds), dim=1)
         dV_ext, dK_ext = torch.empty_like(V_ext), torch.empty_like(K_ext)
         with _lib.device_guard(Q.device):
             _lib.check(L.graphop_spmm_pair(

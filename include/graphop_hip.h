@@ -337,14 +337,16 @@ GRAPHOP_API int graphop_vector_spmm_backward(int dtype, const int64_t* row, cons
  * are streamed once.  The sharded step uses it for its column-major side, whose per-slot weights are a random gather
  * (custom_op_benchmark_amd/dist.py).  X0, X1: (n_x, d); out0, out1: (n_out, d), need not be initialised.
  * Supported (graphop_spmm_pair_supported != 0): fp32, one head, d in {64, 128, 256}, a plan of these arrays with sorted
- * rows, 16-byte-aligned outputs; otherwise GRAPHOP_ERR_INVALID_ARGUMENT -- run the two passes separately. */
+ * rows, 16-byte-aligned outputs; otherwise GRAPHOP_ERR_INVALID_ARGUMENT -- run the two passes separately.
+ * Measured on the column side of a papers100M-shape 1/8 shard (tools/pair_columns_experiment.py): 56.9 ms for the two
+ * separate launches, 52.4 for this one; writing the pairs in the CSR's slot order first so that the weights stream (built,
+ * measured, removed) makes the launch 47.4 ms but the 200 M scattered 8-byte stores cost 8.3. */
 GRAPHOP_API int graphop_spmm_pair_supported(int dtype, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t h,
                                 int64_t d, const graphop_plan_t* plan);
 GRAPHOP_API int graphop_spmm_pair(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,
                       const int64_t* indices, const void* w2, const void* X0, const void* X1, void* out0,
                       void* out1, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t n_out, int64_t h,
                       int64_t d, const graphop_plan_t* plan, void* stream);
-
 /* ---- node_mul_edge_forward(row, indptr, eid, A, B) -> y -------------------------------------
  * replaces graphop.cpp:39-51 / graphop_kernel.cu:235-266 (kernel :19-34).
  * y[eid[j], k] = <A[row[c], k, :], B[eid[j], :]>;  B: (n_edges, d) shared by all heads. */
