@@ -5,12 +5,14 @@
 # per pass: more than that exceeds the hardware's counter slots and rocprofv3 aborts), and the
 # bench lines of the other workloads / input variants.  Copy the files you want judged into profiles/.
 set -eo pipefail
-TAG=${1:-r2_final}
-QUICK=${2:-}
+TAG=${1:-r5_final}
+QUICK=${2:-}          # "quick" = headline only; "variants" / "big" = only that part (a gpurun call is limited to 20 minutes)
+PART=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+if [ "$PART" = "all" ] || [ "$PART" = "quick" ] || [ "$PART" = "headline" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o stats -- \
     python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err"
@@ -32,7 +34,9 @@ python tools/make_traffic_json.py "$OUT/${TAG}_pmc_summary.json" reddit_h1_d64 "
 cp "$OUT/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json
 python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "[refresh] bench done"
-[ -n "$QUICK" ] && { echo "[refresh] quick: done"; exit 0; }
+fi
+[ "$PART" = "quick" ] || [ "$PART" = "headline" ] && { echo "[refresh] headline: done"; exit 0; }
+if [ "$PART" = "all" ] || [ "$PART" = "variants" ]; then
 # input variants of the headline workload: worst-case locality, signed values
 python bench.py --alpha 0 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_alpha0_bench.json" 2>/dev/null
 python bench.py --values normal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_normal_bench.json" 2>/dev/null
@@ -47,6 +51,14 @@ python bench.py --graph harness --d 64 --heads 8 --steps 50 --warmup 5 --no-cpu-
 python bench.py --graph cora --steps 50 --warmup 5 > "$OUT/${TAG}_cora_bench.json" 2>/dev/null
 python bench.py --graph cora --steps 50 --warmup 5 --no-cpu-baseline --hip-graph > "$OUT/${TAG}_cora_hipgraph_bench.json" 2>/dev/null
 echo "[refresh] small shapes done"
+# node labelings (round 5): ids sorted by degree, communities of consecutive ids
+for lab in degree clustered; do
+  python bench.py --labeling $lab --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_reddit_${lab}_bench.json" 2>/dev/null
+  python bench.py --labeling $lab --d 256 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_reddit_${lab}_d256_bench.json" 2>/dev/null
+done
+echo "[refresh] labelings done"
+fi
+[ "$PART" = "variants" ] && { echo "[refresh] variants: done"; exit 0; }
 python tools/tune_sweep.py --fused "" > "$OUT/${TAG}_fused_passes.txt" 2>/dev/null
 python bench.py --graph products --d 16 --heads 8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_products_h8_d16_bench.json" 2>/dev/null
 python bench.py --graph products --d 128 --heads 8 --steps 3 --warmup 1 --cpu-sample-edges 200000 > "$OUT/${TAG}_products_h8_d128_bench.json" 2>/dev/null
