@@ -273,13 +273,13 @@ __global__ __launch_bounds__(kFastBlock, 5) void k_spmm_flat_f32(
 // -- those reads are what separates the column-major passes of a node-range shard from the row-major ones (3.7-4 ms per
 // pass at the papers100M shape, profiles/r4_experiments.txt section 8) -- and the ids, edge ids and chunk metadata are
 // streamed once.  Same chunk ranges, ownership and self-zeroing rules as the single form; twice the rows in flight.
-template <int L, bool SELFZERO>
-__global__ __launch_bounds__(kFastBlock, 3) void k_spmm_flat2_f32(
+template <int L, bool SELFZERO, int U = 4, int BPC = 3>
+__global__ __launch_bounds__(kFastBlock, BPC) void k_spmm_flat2_f32(
     const i64* __restrict__ row, const i64* __restrict__ indptr, const i64* __restrict__ eid,
     const i64* __restrict__ indices, const float2* __restrict__ w, const float* __restrict__ X, const float* __restrict__ X1,
     float* __restrict__ out, float* __restrict__ out1, i64 n_chunks, int chunks_per_group, i64 n_out_rows) {
   constexpr i64 F4 = L;
-  constexpr int U = 4;                               // rows per request burst; two bursts in flight
+  // U rows per request burst and table; two bursts in flight
   static_assert(L % (2 * U) == 0, "the id window moves by whole double bursts");
   const int l = threadIdx.x % L;
   const i64 gid = (i64)blockIdx.x * GroupCfg<L>::kGroupsPerBlock + threadIdx.x / L;
