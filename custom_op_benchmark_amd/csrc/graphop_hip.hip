@@ -1843,11 +1843,6 @@ int graphop_spmm_pair(int dtype, const int64_t* row, const int64_t* indptr, cons
           hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(zb), dim3(kFastBlock), 0, st, (const i64*)row, (float*)out0, n_chunks, cpg);
           hipLaunchKernelGGL((k_zero_shared_rows<L, NV>), dim3(zb), dim3(kFastBlock), 0, st, (const i64*)row, (float*)out1, n_chunks, cpg);
         }
-        if (env_int("GRAPHOP_PAIR_U", 4) == 2)
-          hipLaunchKernelGGL((k_spmm_flat2_f32<L, true, 2, 4>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row, (const i64*)indptr,
-                             (const i64*)eid, (const i64*)indices, (const float2*)w2, (const float*)X0, (const float*)X1,
-                             (float*)out0, (float*)out1, n_chunks, cpg, covered);
-        else
         hipLaunchKernelGGL((k_spmm_flat2_f32<L, true>), dim3(nb), dim3(kFastBlock), 0, st, (const i64*)row, (const i64*)indptr,
                            (const i64*)eid, (const i64*)indices, (const float2*)w2, (const float*)X0, (const float*)X1,
                            (float*)out0, (float*)out1, n_chunks, cpg, covered);
