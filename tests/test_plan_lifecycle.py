@@ -171,3 +171,48 @@ def test_dlpack_arrays_feed_the_ops(dev):
     A = torch.rand(64, 32, device=dev)
     y = ops.maskedmm_csr_forward(g2.row, g2.ptr_r, g2.eid_r, g2.indices_r, A, A)
     assert torch.equal(y, ops.maskedmm_csr_forward(g.row, g.ptr_r, g.eid_r, g.indices_r, A, A))
+
+
+def test_plan_trim_drops_builder_inputs_and_rebuilds_them_on_demand(dev, small_windows):
+    """Round 5 (plan memory): the 32-bit mirrors and a window structure's wp tables are inputs of the layout builders;
+    a plan drops them once a STAGED pass has its dealt layout (plan_trim) and rebuilds them when a builder or a per-batch
+    (non-staged) kernel needs them again, which then PINS them.  One graph, one pair of plans: staged -> per-batch ->
+    staged -> a new geometry -> export; the results never change, the memory goes down, up, and stays."""
+    g = random_graph(1500, 1500, 30000, seed=12, chunk_size=32, zero_rows=0.1, hub=900)
+    inp = rand_inputs(g, 1, 64, seed=13, normal=True)
+    want = oracle_step(oracle, g, inp["Q"], inp["K"], inp["V"], inp["dO"])
+    gd = g.to(dev)
+    args = [inp[k].to(dev) for k in ("Q", "K", "V", "dO")]
+
+    def step():
+        q, k, v = (x.clone().requires_grad_(True) for x in args[:3])
+        s, a, o = functions.attention_step(gd, q, k, v, args[3])
+        torch.cuda.synchronize()
+        for name, got, ref in (("s", s, want["s"]), ("o", o, want["o"]), ("dQ", q.grad, want["dQ"]), ("dK", k.grad, want["dK"]),
+                               ("dV", v.grad, want["dV"])):
+            torch.testing.assert_close(got.detach().cpu(), ref, rtol=1e-4, atol=1e-5, msg=lambda m: name + ": " + m)
+
+    _lib.tune("walk", 0)                        # window-owner kernels for every gather pass: staged strips read dealt copies only
+    _lib.tune("plan_trim", 0); _lib.clear_plan_cache()
+    step()
+    untrimmed = _lib.plan_memory_bytes()
+    _lib.tune("plan_trim", 1); _lib.clear_plan_cache()
+    step()
+    trimmed = _lib.plan_memory_bytes()
+    assert trimmed < untrimmed - 4 * 3 * g.n_edges * 0.9, (trimmed, untrimmed)     # idx32 (x2) + eid32 are gone, and the wp tables
+    _lib.tune("staged_ids", 0)                  # per-batch kernels: they READ the mirrors and the wp tables -> rebuilt and pinned
+    step()
+    pinned = _lib.plan_memory_bytes()
+    assert pinned > trimmed + 4 * 3 * g.n_edges * 0.9
+    _lib.tune("staged_ids", 7)
+    step()
+    assert _lib.plan_memory_bytes() == pinned   # pinned arrays stay (launches on other streams may be reading them)
+    _lib.tune("window_kb", 16)                  # a new geometry on the same plans: its builders find their inputs
+    step()
+    # export after trimming (fresh plans, staged only): the container still holds the full derived state
+    _lib.clear_plan_cache()
+    _lib.tune("window_kb", 8)
+    step()
+    st = _lib.get_plan(gd.row, gd.ptr_r, gd.eid_r, gd.indices_r, g.n_dst).export_state()
+    assert st["idx32"] is not None and torch.equal(st["idx32"].long(), g.indices_r)
+    assert all(sw["wp_lo"] is not None and sw["wp_hi"] is not None for sw in st["sweeps"]) and st["sweeps"]
