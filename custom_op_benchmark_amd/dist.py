@@ -236,6 +236,9 @@ class ShardedAttention:
         self.send_counts = send_counts
         self.serve_rows = serve                                # our rows, grouped by destination peer
         self._serve_groups = None                              # (ptr, rows, pos) of serve_rows, for the HIP add-home kernel
+        # every rank must take the SAME exchange form in a step (a grouped send / recv on one rank does not match an
+        # all_to_all_single on another): what pack_kv = "auto" decides on is therefore the largest exchange of ANY rank
+        self._max_exchange_rows = self._all_reduce_max(max(self.n_halo, int(serve.numel())))
         self.fwd_halves = self._cut_forward_halves(chunk_size) if (self.split_forward and self.n_halo > 0) else None
 
     def _cut_forward_halves(self, chunk_size):
@@ -270,6 +273,18 @@ class ShardedAttention:
             t_in, t_out = t_in.cpu(), t_out.cpu()
         dist.all_to_all_single(t_out, t_in, group=self.group)
         return t_out.tolist()
+
+    def _all_reduce_max(self, v):
+        """max of an int over the ranks (setup-time collective; the local value without peers)."""
+        if (self.world == 1 and not self.force) or self.emulate:
+            return int(v)
+        if self.local is not None:
+            return max(self.local.group.exchange_counts(self.rank, [int(v)] * self.world))
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
     def _timed(self, name, fn):
         """Wall time of one exchange incl. device completion (only when self.timers is a dict: the
@@ -349,8 +364,8 @@ class ShardedAttention:
         return _Works([self._all_to_all(o, i, out_splits, in_splits, async_op) for o, i in pairs])
 
     def _pack_kv_now(self, row_bytes):
-        if self.pack_kv == "auto":
-            return max(self.n_halo, int(self.serve_rows.numel())) * row_bytes <= PACK_KV_MAX_BYTES
+        if self.pack_kv == "auto":      # (decided from the largest exchange of any rank: the same answer on every rank)
+            return self._max_exchange_rows * row_bytes <= PACK_KV_MAX_BYTES
         return bool(self.pack_kv)
 
     def gather_halos_grouped(self, pairs, async_op=False, role="KV"):
@@ -590,8 +605,13 @@ class ShardedAttention:
         import time
         cuda = self.device.type == "cuda"
         real = self.world > 1 and self.local is None and not self.emulate
-        fus = [False] + ([True] if self._columns_fusable(Q.detach().contiguous(), torch.empty(0, device=self.device)) else [])
-        packs = [False, True] if (self.n_halo > 0 or self.force) else [False]
+        # the candidate list must be the SAME on every rank (each candidate is a fixed number of collective steps): what a
+        # rank supports is reduced over the ranks first
+        fusable = self._columns_fusable(Q.detach().contiguous(), torch.empty(0, device=self.device))
+        fusable = bool(-self._all_reduce_max(0 if fusable else 1) + 1)        # AND over the ranks
+        exchanging = bool(self._all_reduce_max(1 if (self.n_halo > 0 or self.force) else 0))
+        fus = [False] + ([True] if fusable else [])
+        packs = [False, True] if exchanging else [False]
         cands = candidates or [(p, f) for f in fus for p in packs]
 
         def sync():
