@@ -78,6 +78,7 @@ _SIGNATURES = {
     "graphop_vector_spmm_backward": [ctypes.c_int] + [_P] * 13 + [_c64] * 7 + [_P, _P, _P],
     "graphop_spmm_pair_supported": [ctypes.c_int] + [_c64] * 5 + [_P],
     "graphop_spmm_pair": [ctypes.c_int] + [_P] * 9 + [_c64] * 6 + [_P, _P],
+    "graphop_interleave_pairs": [ctypes.c_int, _P, _P, _P, _c64, _P],
     "graphop_node_mul_edge_forward": [ctypes.c_int] + [_P] * 6 + [_c64] * 5 + [_P, _P],
     "graphop_node_mul_edge_backward": [ctypes.c_int] + [_P] * 8 + [_c64] * 5 + [_P, _P],
     "graphop_gather_rows": [ctypes.c_int, _P, _P, _P, _c64, _c64, _c64, _P],

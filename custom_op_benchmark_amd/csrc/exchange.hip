@@ -89,12 +89,42 @@ inline unsigned grid_of(i64 total) {
   return (unsigned)(g > 65536 ? 65536 : g);
 }
 
+// out2[i] = (w0[i], w1[i]): two per-edge arrays interleaved into the (n, 2) pairs graphop_spmm_pair reads (streaming;
+// torch.stack does the same at a third of the rate)
+__global__ __launch_bounds__(256) void k_interleave_pairs(const float4* __restrict__ w0, const float4* __restrict__ w1,
+                                                          float4* __restrict__ out2, i64 n4, const float* __restrict__ t0,
+                                                          const float* __restrict__ t1, float2* __restrict__ tout, int n_tail) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (i64)gridDim.x * blockDim.x) {
+    const float4 a = w0[i], b = w1[i];
+    out2[2 * i] = make_float4(a.x, b.x, a.y, b.y);
+    out2[2 * i + 1] = make_float4(a.z, b.z, a.w, b.w);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tout[threadIdx.x] = make_float2(t0[threadIdx.x], t1[threadIdx.x]);
+}
+
 }  // namespace
 }  // namespace graphop
 
 using namespace graphop;
 
 extern "C" {
+
+int graphop_interleave_pairs(int dtype, const void* w0, const void* w1, void* out2, int64_t n, void* stream) {
+  const char* fn = "interleave_pairs";
+  GO_CHECK_ARG(dtype == GRAPHOP_F32, "%s: fp32 only", fn);
+  GO_CHECK_ARG(n >= 0, "%s: negative size", fn);
+  if (n == 0) return GRAPHOP_OK;
+  GO_PTR(fn, w0); GO_PTR(fn, w1); GO_PTR(fn, out2);
+  GO_CHECK_ARG((((uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)out2) & 15) == 0, "%s: 16-byte-aligned arrays", fn);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof("interleave_pairs", st, "k_interleave_pairs");
+  const i64 n4 = n / 4;
+  const int tail = (int)(n - 4 * n4);
+  hipLaunchKernelGGL(k_interleave_pairs, dim3(grid_of(n4 > 0 ? n4 : 1)), dim3(256), 0, st, (const float4*)w0, (const float4*)w1,
+                     (float4*)out2, n4, (const float*)w0 + 4 * n4, (const float*)w1 + 4 * n4, (float2*)out2 + 4 * n4, tail);
+  GO_LAUNCH_CHECK();
+  return GRAPHOP_OK;
+}
 
 int graphop_gather_rows(int dtype, const void* src, const int64_t* idx, void* dst, int64_t n_idx,
                         int64_t n_src_rows, int64_t row_elems, void* stream) {

@@ -574,9 +574,10 @@ class ShardedAttention:
         # (a, ds) as (E, 2) pairs: a slot's two weights are ONE 8-byte random read in the column pass (scattering them into
         # the column CSR's slot order first so that they stream was built and measured: the 200 M scattered 8-byte stores
         # cost 8.3 ms for a 5 ms faster pass -- profiles/r5_pair_columns_experiment.txt)
-        w2 = torch.stack((a, ds), dim=1)
+        w2 = torch.empty((g.n_edges, 2), dtype=a.dtype, device=a.device)
         dV_ext, dK_ext = torch.empty_like(V_ext), torch.empty_like(K_ext)
         with _lib.device_guard(Q.device):
+            _lib.check(L.graphop_interleave_pairs(_lib.F32, _lib.ptr(a), _lib.ptr(ds), _lib.ptr(w2), g.n_edges, st))
             _lib.check(L.graphop_spmm_pair(
                 _lib.F32, _lib.ptr(g.col), _lib.ptr(g.ptr_c), _lib.ptr(g.eid_c), _lib.ptr(g.indices_c), _lib.ptr(w2), _lib.ptr(dO),
                 _lib.ptr(Q), _lib.ptr(dV_ext), _lib.ptr(dK_ext), g.col.size(0), g.n_edges, Q.size(0), K_ext.size(0), 1, d,

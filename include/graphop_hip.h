@@ -341,6 +341,9 @@ GRAPHOP_API int graphop_vector_spmm_backward(int dtype, const int64_t* row, cons
  * Measured on the column side of a papers100M-shape 1/8 shard (tools/pair_columns_experiment.py): 56.9 ms for the two
  * separate launches, 52.4 for this one; writing the pairs in the CSR's slot order first so that the weights stream (built,
  * measured, removed) makes the launch 47.4 ms but the 200 M scattered 8-byte stores cost 8.3. */
+/* out2[i] = (w0[i], w1[i]), i < n: two fp32 per-edge arrays interleaved into the (n, 2) pairs graphop_spmm_pair reads
+ * (16-byte-aligned arrays; a streaming kernel). */
+GRAPHOP_API int graphop_interleave_pairs(int dtype, const void* w0, const void* w1, void* out2, int64_t n, void* stream);
 GRAPHOP_API int graphop_spmm_pair_supported(int dtype, int64_t n_chunks, int64_t n_edges, int64_t n_x, int64_t h,
                                 int64_t d, const graphop_plan_t* plan);
 GRAPHOP_API int graphop_spmm_pair(int dtype, const int64_t* row, const int64_t* indptr, const int64_t* eid,

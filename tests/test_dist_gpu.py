@@ -256,7 +256,7 @@ def test_spmm_pair_entry_vs_oracle(dev):
     _lib.tune_reset(); _lib.clear_plan_cache()
     for d, cs, cpg in ((64, 1, 3), (128, 32, 32), (256, 2, 70), (128, 1, 5)):
         _lib.tune("spmm_flat_cpg", cpg)
-        g = random_graph(900, 1400, 2600, seed=d + cs, chunk_size=cs, zero_rows=0.0, hub=700)
+        g = random_graph(900, 1400, 2600 + cs, seed=d + cs, chunk_size=cs, zero_rows=0.0, hub=700)
         gen = torch.Generator().manual_seed(d)
         X0, X1 = torch.randn(g.n_src, d, generator=gen), torch.randn(g.n_src, d, generator=gen)
         w0, w1 = torch.rand(g.n_edges, generator=gen), torch.randn(g.n_edges, generator=gen)
@@ -265,7 +265,11 @@ def test_spmm_pair_entry_vs_oracle(dev):
         want0 = orc.vector_spmm_forward(g.col, g.ptr_c, g.eid_c, g.indices_c, w0, pad(X0))[:n_out]
         want1 = orc.vector_spmm_forward(g.col, g.ptr_c, g.eid_c, g.indices_c, w1, pad(X1))[:n_out]
         gd = g.to(dev)
-        w2 = torch.stack((w0, w1), dim=1).to(dev)
+        w0d, w1d = w0.to(dev), w1.to(dev)
+        w2 = torch.full((g.n_edges, 2), float("nan"), device=dev)
+        _lib.check(_lib.lib().graphop_interleave_pairs(_lib.F32, _lib.ptr(w0d), _lib.ptr(w1d), _lib.ptr(w2), g.n_edges,
+                                                       _lib.stream_of(w2)))
+        assert torch.equal(w2, torch.stack((w0d, w1d), dim=1))          # (n not a multiple of 4: the tail lanes)
         X0d, X1d = X0.to(dev), X1.to(dev)
         out0 = torch.full((n_out, d), float("nan"), device=dev)
         out1 = torch.full((n_out, d), float("nan"), device=dev)
