@@ -290,6 +290,51 @@ def test_papers100m_shard_properties(dev):
     assert prof["sddmm_bwd_dA"]["kernel"] == "k_spmm_f32", prof
 
 
+def test_papers100m_shard_step_forms_agree(dev):
+    """BASELINE config 4 at full shard size, the round-5 forms of the sharded step against the round-4 one on the same
+    inputs (one-GPU rehearsal: exchanges are local copies, the same in every form): the SDDMM forward as own-column +
+    halo-column halves writes the SAME scores bit for bit (every score is computed by one lane group either way), and
+    the column-major backward passes as one launch (graphop_spmm_pair) give the same dK / dV up to summation order."""
+    from custom_op_benchmark_amd.dist import ShardedAttention
+    import gc; gc.collect(); torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 150 << 30:
+        pytest.skip("needs ~120 GB of free HBM")
+    n_per_rank, e_per_rank = 111_059_956 // 8, 1_615_685_872 // 8
+    sh = ShardedAttention.synthetic(n_per_rank, e_per_rank, 8, 0, dev, alpha=0.5, seed=0, timing_only=True, cut=0.1)
+    assert sh.fwd_halves is not None
+    own, halo = sh.fwd_halves
+    assert own["slots"].numel() + halo["slots"].numel() == sh.graph.n_edges and halo["slots"].numel() > 0.05 * sh.graph.n_edges
+    d = 128
+    gen = torch.Generator(device=dev).manual_seed(3)
+    Q = torch.rand(sh.n_own, d, device=dev, generator=gen)
+    K = sh.own_rows_view("K", (d,)).copy_(torch.rand(sh.n_own, d, device=dev, generator=gen))
+    V = sh.own_rows_view("V", (d,)).copy_(torch.rand(sh.n_own, d, device=dev, generator=gen))
+    dO = torch.rand(sh.n_own, d, device=dev, generator=gen)
+    _lib.profile_enable(True)
+    try:
+        sh.fuse_columns = True
+        r1 = sh.step(Q, K, V, dO)
+        torch.cuda.synchronize()
+        tags = set(_lib.profile_read())
+        assert {"sddmm_fwd_part", "spmm_pair_cols", "interleave_pairs"} <= tags and "spmm_bwd_dx" not in tags, tags
+        keep = {k: r1[k].clone() for k in ("s", "o", "dQ", "dK", "dV")}
+        del r1
+        halves, sh.fwd_halves, sh.fuse_columns = sh.fwd_halves, None, False
+        r0 = sh.step(Q, K, V, dO)
+        torch.cuda.synchronize()
+        tags = set(_lib.profile_read())
+        assert {"sddmm_fwd", "spmm_bwd_dx", "sddmm_bwd_dB"} <= tags and "spmm_pair_cols" not in tags, tags
+        sh.fwd_halves = halves
+    finally:
+        _lib.profile_enable(False)
+    assert torch.equal(keep["s"], r0["s"])
+    assert torch.equal(keep["o"], r0["o"]) and torch.equal(keep["dQ"], r0["dQ"])       # same kernels on the same scores
+    for k in ("dK", "dV"):
+        torch.testing.assert_close(keep[k], r0[k], rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
+    graphs.release(sh.graph)
+
+
 def test_rmat25_shard_properties(dev):
     """BASELINE config 5: rank 0 of 8 of the R-MAT scale-25 graph (the densest node range: rows of 10^5-10^6
     slots), d = 256."""
