@@ -329,8 +329,7 @@ def test_papers100m_shard_step_forms_agree(dev):
     finally:
         _lib.profile_enable(False)
     assert torch.equal(keep["s"], r0["s"])
-    assert torch.equal(keep["o"], r0["o"]) and torch.equal(keep["dQ"], r0["dQ"])       # same kernels on the same scores
-    for k in ("dK", "dV"):
+    for k in ("o", "dQ", "dK", "dV"):     # (rows cut between two lane groups are merged by float atomics: not bitwise)
         torch.testing.assert_close(keep[k], r0[k], rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
     graphs.release(sh.graph)
 
