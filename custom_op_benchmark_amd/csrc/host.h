@@ -123,7 +123,7 @@ struct Tuning {
 Tuning& tuning_mut();
 const Tuning& tuning();
 
-// Stream-ordered zero fill (a kernel, see kernels_generic.h: k_zero16).
+// Stream-ordered zero fill (a kernel: runtime.hip, k_zero16).
 hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st);
 
 struct SweepView;   // kernels_fast.h
@@ -158,6 +158,17 @@ struct SweepOpts {
 int choose_sweep(const graphop_plan* plan, i64 n_table_rows, int L, int NV, hipStream_t st,
                  SweepLaunch* out, bool accumulating = false, const SweepOpts* opts = nullptr);
 
+// plan.hip (setup kernels and the plan's cached structures)
+int partition_count(const i64*, i64, i64, i64*, hipStream_t);
+int partition_fill(const i64*, const i64*, i64, i64, i64, i64*, i64*, hipStream_t);
+int plan_build(graphop_plan*, i64, hipStream_t, int);
+int plan_get_sweep(graphop_plan*, int, i64, int, hipStream_t, const Sweep**);
+int* plan_take_queue(graphop_plan*, const Sweep*);
+int plan_get_dealt(graphop_plan*, const Sweep*, int, int, hipStream_t, const Sweep::Dealt**, bool want_eids = true);
+void plan_free_sweeps(graphop_plan*);
+int plan_get_walk(graphop_plan*, int, i64, int, int, int, int, hipStream_t, const Walk**, bool want_widx = true);
+int plan_build_seg_eptr(graphop_plan*, hipStream_t);
+int* plan_take_walk_sync(graphop_plan*, const Walk*);
 int plan_n_sweeps(const graphop_plan* p);
 const Sweep* plan_sweep_at(const graphop_plan* p, int i);
 int plan_import_arrays(graphop_plan* p, const i64* seg_chunk, const int32_t* idx32, const int32_t* eid32,

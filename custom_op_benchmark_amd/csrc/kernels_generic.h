@@ -147,20 +147,6 @@ __global__ __launch_bounds__(kGenericBlock) void k_node_mul_edge_bwd_b(
     }
 }
 
-// Zero fill as a kernel.  hipMemsetAsync is not used on the data path: as a memset node of a
-// captured HIP graph (ROCm 7.2) it left half of the dwords of the byte range untouched on replay.
-__global__ void k_zero16(uint4* __restrict__ p, i64 n16, unsigned char* __restrict__ tail, int n_tail) {
-  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  if (i < n_tail) tail[i] = 0;
-  for (; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-__global__ void k_zero1(unsigned char* __restrict__ p, i64 n) {
-  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = 0;
-}
-
 // ---- sparse softmax, general layout: the reference's three passes with native atomics ----------
 template <typename T>
 __global__ void k_fill(T* p, i64 n, T v) {
