@@ -327,7 +327,8 @@ def main():
     schedule = None
     if runner is not None and not args.no_autotune:
         schedule = runner.autotune(Q, K, V, dO, steps=2)
-        log("schedules (ms per step, max over ranks): %s -> kv_packed=%s columns_fused=%s" % (schedule, runner.pack_kv, runner.fuse_columns))
+        log("schedules (ms per step, max over ranks): %s -> kv_packed=%s columns_fused=%s forward_split=%s"
+            % (schedule, runner.pack_kv, runner.fuse_columns, runner.use_forward_split))
     for _ in range(args.warmup):
         step()
 
@@ -643,6 +644,7 @@ def main():
                                     "without halo)" % ("4" if name == "papers100m" else "5" if name == "rmat25" else "?", name, name))
         cfg["halo"] = runner.halo_stats(h * d * 4)
         cfg["schedule"] = {"kv_packed": bool(cfg["halo"]["kv_packed"]), "columns_fused": bool(runner.fuse_columns),
+                           "forward_split": bool(cfg["halo"]["forward_split"]),
                            "measured_ms_per_step": schedule,
                            "how": ("dist.ShardedAttention.autotune: every schedule timed for 2 steps after a warm-up, max over "
                                    "ranks, fastest adopted by all ranks" if schedule else "default (--no-autotune)")}

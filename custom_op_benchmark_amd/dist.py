@@ -198,6 +198,9 @@ class ShardedAttention:
         # and share the dQ pass as cover (split form: dV travels under softmax-backward + the dK pass, dK under dQ), so
         # which form is faster depends on the links: autotune() measures both.  HIP path, fp32, one head, d in {64,128,256}.
         self.fuse_columns = os.environ.get("GRAPHOP_DIST_FUSE_COLUMNS", "0") == "1"
+        # whether step() USES the forward halves it cut (autotune: the halo half re-reads the Q row of every row that has
+        # a halo slot -- ~2 ms at the papers100M shape -- which only pays where there is an exchange to hide)
+        self.use_forward_split = True
         self.noop_exchange = False        # bench.py: exchanges do nothing at all (timing only: what a step costs without them)
         self.collectives_last_step = 0
         self.device = torch.device(device)
@@ -477,7 +480,7 @@ class ShardedAttention:
             wait_v = self.gather_halo_into(Vd, V_ext, async_op=True, role="V")
         a4 = (g.row, g.ptr_r, g.eid_r, g.indices_r)
         a8 = g.csr_args()
-        if self.fwd_halves is not None:
+        if self.fwd_halves is not None and self.use_forward_split:
             # own-column half while the K rows travel (it gathers K_ext[:n_own] only), halo-column half behind the wait
             s = self._sddmm_forward_halves(Qd, K_ext, wait_k)
         else:
@@ -598,7 +601,8 @@ class ShardedAttention:
 
     def autotune(self, Q, K, V, dO, steps=2, candidates=None):
         """Measure, don't guess: the step under every schedule the shard supports -- K | V halo rows as one grouped
-        exchange or two, the column-major backward passes as one launch or two -- `steps` steps each after one warm-up,
+        exchange or two, the column-major backward passes as one launch or two, the SDDMM forward as own / halo halves
+        (K exchange hidden, Q rows of the halo half re-read) or whole -- `steps` steps each after one warm-up,
         wall time between barriers, MAX over ranks; the fastest is adopted by EVERY rank (the choice is made from the
         reduced times, so all ranks agree).  Which one wins depends on the links: packing delays the halo half of the
         SDDMM until V has arrived too, fusing the columns leaves both gradient exchanges only the dQ pass as cover.
@@ -611,9 +615,11 @@ class ShardedAttention:
         fusable = self._columns_fusable(Q.detach().contiguous(), torch.empty(0, device=self.device))
         fusable = bool(-self._all_reduce_max(0 if fusable else 1) + 1)        # AND over the ranks
         exchanging = bool(self._all_reduce_max(1 if (self.n_halo > 0 or self.force) else 0))
+        splittable = bool(-self._all_reduce_max(0 if self.fwd_halves is not None else 1) + 1)
         fus = [False] + ([True] if fusable else [])
         packs = [False, True] if exchanging else [False]
-        cands = candidates or [(p, f) for f in fus for p in packs]
+        splits = [True, False] if splittable else [False]
+        cands = candidates or [(p, f, sp) for sp in splits for f in fus for p in packs]
 
         def sync():
             if real:
@@ -622,23 +628,26 @@ class ShardedAttention:
                 torch.cuda.synchronize(self.device)
 
         times = {}
-        for pack, fuse in cands:
-            self.pack_kv, self.fuse_columns = pack, fuse
+        for cand in cands:
+            pack, fuse = cand[0], cand[1]
+            split = cand[2] if len(cand) > 2 else self.use_forward_split
+            self.pack_kv, self.fuse_columns, self.use_forward_split = pack, fuse, split
             self.step(Q, K, V, dO)
             sync()
             t0 = time.perf_counter()
             for _ in range(steps):
                 self.step(Q, K, V, dO)
             sync()
-            times[(pack, fuse)] = (time.perf_counter() - t0) / steps
+            times[(pack, fuse, split)] = (time.perf_counter() - t0) / steps
         keys = sorted(times)
         t = torch.tensor([times[k] for k in keys], dtype=torch.float64,
                          device=self.device if (real and dist.get_backend(self.group) == "nccl") else "cpu")
         if real:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         best = keys[int(torch.argmin(t))]
-        self.pack_kv, self.fuse_columns = best
-        return {"kv_%s+columns_%s" % ("packed" if k[0] else "separate", "fused" if k[1] else "split"): round(1e3 * float(v), 3)
+        self.pack_kv, self.fuse_columns, self.use_forward_split = best
+        return {"kv_%s+columns_%s+forward_%s" % ("packed" if k[0] else "separate", "fused" if k[1] else "split",
+                                                  "split" if k[2] else "whole"): round(1e3 * float(v), 3)
                 for k, v in zip(keys, t.tolist())}
 
     def _sddmm_forward_halves(self, Q, K_ext, wait_k):
@@ -730,7 +739,7 @@ class ShardedAttention:
                 "bytes_per_exchange_in": self.n_halo * row_bytes,
                 "bytes_per_exchange_out": int(self.serve_rows.numel()) * row_bytes,
                 "exchanges_per_step": 4, "collectives_last_step": self.collectives_last_step,
-                "kv_packed": self._pack_kv_now(row_bytes), "forward_split": self.fwd_halves is not None,
+                "kv_packed": self._pack_kv_now(row_bytes), "forward_split": self.fwd_halves is not None and self.use_forward_split,
                 "columns_fused": bool(self.fuse_columns)}
 
     # ---- builders --------------------------------------------------------------------------------

@@ -51,9 +51,9 @@ def _worker(rank, world, port, h, d, out_dir, pack_kv, split_forward):
         if world == 3:
             # autotune: both exchange schedules timed, max over ranks, every rank adopts the same one
             times = sh.autotune(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi], steps=1)
-            assert set(times) == {"kv_separate+columns_split", "kv_packed+columns_split"}
+            assert set(times) == {"kv_%s+columns_split+forward_%s" % (k, f) for k in ("separate", "packed") for f in ("split", "whole")}
             picks = [None] * world
-            dist.all_gather_object(picks, (sh.pack_kv, sh.fuse_columns, sorted(times.items())))
+            dist.all_gather_object(picks, (sh.pack_kv, sh.fuse_columns, sh.use_forward_split, sorted(times.items())))
             assert all(p == picks[0] for p in picks), picks
             r2 = sh.step(inp["Q"][lo:hi], inp["K"][lo:hi], inp["V"][lo:hi], inp["dO"][lo:hi])
             for k in ("o", "dQ", "dK", "dV"):

@@ -313,7 +313,7 @@ def test_papers100m_shard_step_forms_agree(dev):
     dO = torch.rand(sh.n_own, d, device=dev, generator=gen)
     _lib.profile_enable(True)
     try:
-        sh.fuse_columns = True
+        sh.fuse_columns, sh.use_forward_split = True, True
         r1 = sh.step(Q, K, V, dO)
         torch.cuda.synchronize()
         tags = set(_lib.profile_read())
