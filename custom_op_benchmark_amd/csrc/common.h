@@ -63,7 +63,6 @@ int check_not_capturing(hipStream_t st, const char* what);
 // the host looks at it at the start of every entry point and in graphop_check_device_errors (graphop_hip.hip).
 int* device_error_word(bool create);   // device-visible pointer (nullptr when there is none yet and !create)
 int check_async_error(bool clear = false);   // GRAPHOP_OK, or GRAPHOP_ERR_HIP with the message set; the record is sticky unless clear
-int tuning_merge_sparse_min();             // knob merge_sparse_min (host.h: Tuning), for plan.hip
 int tuning_plan_trim();                   // knob plan_trim (host.h: Tuning), for plan.hip
 int walk_launch_id(const char* tag);     // sequence number of the walk launch about to be made under this pass tag
 

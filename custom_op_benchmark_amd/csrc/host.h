@@ -63,8 +63,6 @@ struct Tuning {
   int walk_debug;         // 1: every walk launch is followed by a synchronisation and a line of pacing statistics on stderr
   int walk_fault;         // tests only: inject a hand-over fault into the walk kernel (kernels_walk.h: WalkView::fault)
   int walk_blocks;        // > 0: workgroups of the walk launches (tests: a small grid makes several rounds of sizeable bins)
-  int merge_sparse_min;   // dealt layouts: runs of adjacent windows whose (window, tile) tasks hold fewer slots than this become one
-                          // task (plan.hip: k_merge_sparse_windows); 0 = every window its own task (rounds 2-4)
   int plan_trim;          // 1: plans drop what only their layout builders read (32-bit mirrors, window tables) once an op has what
                           // it launches with; rebuilt on demand (plan.hip: plan_trim)
   int n_cu;
@@ -109,7 +107,6 @@ struct Tuning {
     walk_debug = env_int("GRAPHOP_WALK_DEBUG", 0);
     walk_fault = 0;
     plan_trim = env_int("GRAPHOP_PLAN_TRIM", 1);
-    merge_sparse_min = env_int("GRAPHOP_MERGE_SPARSE_MIN", 256);
     n_cu = 256;
     int dev = 0;
     hipDeviceProp_t prop;

@@ -228,65 +228,6 @@ __global__ void k_sweep_fill(const i64* __restrict__ vr_seg, const i64* __restri
 
 // ---- dealt (window-major) task layout ---------------------------------------------------------------
 // One wave per (window w, tile t).  Same deal as the run-time one (kernels_fast.h, WownTask::load):
-// Sparse (window, tile) tasks merged (round 5).  On graphs whose neighbour ids cluster (communities of consecutive ids: most
-// real graphs after a locality ordering) a tile's rows have nearly all their slots in ONE window and a handful in each of
-// the others: 15 of 16 tasks of a tile hold a few dozen slots, and their per-task cost (queue pull, records, A rows, id
-// stage prologue) is what the window-owner passes then spend their time on (clustered Reddit shape: SDDMM-type passes 1.69
-// against 1.47 ms on the shuffled graph, while the walk passes GAIN 15 % from the same locality).  Ids ascend inside a row,
-// so the slots of ADJACENT windows are one contiguous range: this pass rewrites a copy of the window tables per tile --
-// runs of adjacent windows whose tasks hold fewer than `min_slots` slots become ONE task (the first window of the run takes
-// the merged ranges, the others become empty); windows at or above the threshold stay alone (their gathers are what the
-// L2 window is for).  A vrow that is a PIECE of a long row (its slots of adjacent windows are not adjacent) keeps its
-// per-window granules.  One wave per tile.  Graphs without sparse tasks (the shuffled shapes) get identical tables.
-__global__ __launch_bounds__(256) void k_merge_sparse_windows(const int* __restrict__ wp_lo, const int* __restrict__ wp_hi,
-                                                              int V, int W, int tile, int min_slots,
-                                                              int* __restrict__ out_lo, int* __restrict__ out_hi) {
-  const int lane = threadIdx.x & 63;
-  const i64 t = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const i64 tiles = ((i64)V + tile - 1) / tile;
-  if (t >= tiles) return;
-  const i64 v = t * tile + lane;
-  const bool live = lane < tile && v < V;
-  auto wave_sum = [&](int x) { for (int off = 1; off < 64; off <<= 1) x += __shfl_xor(x, off); return x; };
-  int wa = -1;                 // first window of the open sparse run (-1: none)
-  int acc = 0;                 // slots of the open run (whole tile)
-  int g_lo = 0, g_hi = 0;      // this vrow's merged range over the open run
-  bool contig = true;          // ... is one contiguous range so far
-  auto close = [&](int wb) {   // windows wa .. wb become one task
-    if (wa < 0) return;
-    if (live) {
-      if (contig) {
-        out_lo[(i64)wa * V + v] = g_lo; out_hi[(i64)wa * V + v] = g_hi;
-        for (int w = wa + 1; w <= wb; ++w) { out_lo[(i64)w * V + v] = g_hi; out_hi[(i64)w * V + v] = g_hi; }
-      } else {
-        for (int w = wa; w <= wb; ++w) { out_lo[(i64)w * V + v] = wp_lo[(i64)w * V + v]; out_hi[(i64)w * V + v] = wp_hi[(i64)w * V + v]; }
-      }
-    }
-    wa = -1; acc = 0; contig = true;
-  };
-  for (int w = 0; w < W; ++w) {
-    int lo = 0, hi = 0;
-    if (live) { lo = wp_lo[(i64)w * V + v]; hi = wp_hi[(i64)w * V + v]; }
-    const int c = wave_sum(hi - lo);
-    if (c >= min_slots) {                       // a window worth its own task
-      close(w - 1);
-      if (live) { out_lo[(i64)w * V + v] = lo; out_hi[(i64)w * V + v] = hi; }
-      continue;
-    }
-    if (wa < 0) { wa = w; g_lo = lo; g_hi = hi; contig = true; }
-    else {
-      if (hi > lo) {                            // (empty granules join any run)
-        if (g_hi == g_lo) { g_lo = lo; g_hi = hi; }
-        else if (lo == g_hi) g_hi = hi;
-        else contig = false;
-      }
-    }
-    acc += c;
-    if (acc >= min_slots) close(w);
-  }
-  close(W - 1);
-}
-
 // rank the tile's granules by length (longest first, ties by lane) and hand them to the wave's GW
 // lane groups in snake order; record (g, k) = (first slot, length, row id, 0) at
 // rec[((w * tiles + t) * tile + g * K + k)] and the group's total, rounded up to 4, at strip_len.
@@ -1009,20 +950,7 @@ int plan_get_dealt(graphop_plan* p, const Sweep* sw, int L, int K, hipStream_t s
   }
   auto fail = [&](int rc) { go_free(d.rec); go_free(d.ids); go_free(d.eids); return rc; };
   const unsigned grid = (unsigned)ceil_div(tasks, 4);
-  // window tables with the sparse tasks of every tile merged (temporaries: the plan keeps the per-window tables)
-  const int* wlo = s->wp_lo;
-  const int* whi = s->wp_hi;
-  DevBuf mlo, mhi;
-  const int min_slots = tuning_merge_sparse_min();
-  if (min_slots > 0 && s->W > 1) {
-    const size_t wp_bytes = sizeof(int) * (size_t)s->V * (size_t)s->W;
-    if (go_malloc(&mlo.p, wp_bytes, st) != hipSuccess || go_malloc(&mhi.p, wp_bytes, st) != hipSuccess) return fail(GRAPHOP_ERR_HIP);
-    hipLaunchKernelGGL(k_merge_sparse_windows, dim3((unsigned)ceil_div(tiles, 4)), dim3(256), 0, st, s->wp_lo, s->wp_hi, s->V, s->W,
-                       tile, min_slots, (int*)mlo.p, (int*)mhi.p);
-    if (hipGetLastError() != hipSuccess) return fail(GRAPHOP_ERR_HIP);
-    wlo = (const int*)mlo.p; whi = (const int*)mhi.p;
-  }
-  hipLaunchKernelGGL(k_deal_records, dim3(grid), dim3(256), 0, st, wlo, whi, s->vr_row, s->V, s->W,
+  hipLaunchKernelGGL(k_deal_records, dim3(grid), dim3(256), 0, st, s->wp_lo, s->wp_hi, s->vr_row, s->V, s->W,
                      L, K, (int)tiles, (int4*)d.rec, (int*)len.p);
   if (hipGetLastError() != hipSuccess) return fail(GRAPHOP_ERR_HIP);
   size_t tmp_bytes = 0;

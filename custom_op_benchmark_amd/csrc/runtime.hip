@@ -132,7 +132,6 @@ Tuning& tuning_mut() {
 }
 const Tuning& tuning() { return tuning_mut(); }
 int tuning_plan_trim() { return tuning().plan_trim; }
-int tuning_merge_sparse_min() { return tuning().merge_sparse_min; }
 
 // Stream-ordered zero fill (a kernel: runtime.hip, k_zero16).
 hipError_t zero_async(void* ptr, size_t bytes, hipStream_t st) {
@@ -239,7 +238,7 @@ std::vector<TuneEntry> tune_table() {
       {"spmm_flat_min_chunks", &t.spmm_flat_min_chunks}, {"staged_ids", &t.staged_ids}, {"attn_max_d", &t.attn_max_d},
       {"touch_sddmm", &t.touch_sddmm}, {"walk", &t.walk}, {"walk_window_kb", &t.walk_window_kb}, {"walk_window_kb_col", &t.walk_window_kb_col},
       {"walk_drift", &t.walk_drift}, {"walk_min_bin", &t.walk_min_bin}, {"walk_blocks", &t.walk_blocks}, {"walk_debug", &t.walk_debug}, {"walk_fault", &t.walk_fault}, {"walk_steps", &t.walk_steps},
-      {"plan_trim", &t.plan_trim}, {"merge_sparse_min", &t.merge_sparse_min}};
+      {"plan_trim", &t.plan_trim}};
 }
 }  // namespace
 

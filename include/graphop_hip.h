@@ -110,8 +110,7 @@ GRAPHOP_API int graphop_check_device_errors(void);
  * flushed per window), walk_window_kb, walk_window_kb_col, walk_drift, walk_steps, walk_min_bin,
  * walk_blocks, walk_debug, walk_fault (tests: hand-over fault injection), spmm_selfzero, spmm_selfzero_min_mb
  * (row-owning chunk driver defines every output row itself: no zero fill of outputs of at least that many MB),
- * plan_trim (0/1: plans drop builder inputs no kernel reads, see "device memory of plans"), merge_sparse_min (window-owner
- * passes: adjacent windows whose (window, row tile) tasks hold fewer slots than this are merged into one task; 0 = off), spmm_flat (0/1), spmm_flat_max_mean, spmm_flat_min_chunks, spmm_flat_cpg (that driver in its slot-walking form below
+ * plan_trim (0/1: plans drop builder inputs no kernel reads, see "device memory of plans"), spmm_flat (0/1), spmm_flat_max_mean, spmm_flat_min_chunks, spmm_flat_cpg (that driver in its slot-walking form below
  * that many slots per chunk on average, for chunk lists at least that long, with that many chunks per lane group).  Not thread-safe against
  * concurrent op calls; results never depend on them.  (Removed in ABI 6: sweep_mode, sweep_drift,
  * sweep_prefetch, transpose_scalars -- the paced vrow-owner sweep and the scalar transpose pre-pass,
