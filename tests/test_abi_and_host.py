@@ -197,3 +197,27 @@ def test_cpp_extension_mirrors_the_reference_module():
         torch.ops.graphop.attention_forward(i, i, i, i, f, f, f)
     with pytest.raises(TypeError):
         ext.sparse_softmax_forward(i, i, i)            # positional signature, 4 arguments (graphop.cpp:59-63)
+
+
+def test_head_group_rule_and_labelings():
+    """Host logic of round 5: FusedAttention's head-group size (256-B rows, one head per group from d = 64 on, blocking only
+    where it saves memory) and the generator's node labelings (bench.py --labeling)."""
+    import torch
+    from custom_op_benchmark_amd import functions, graphs
+    hg = functions._head_group
+    assert [hg(8, 32), hg(8, 16), hg(8, 64), hg(8, 128), hg(2, 32), hg(6, 16), hg(3, 16)] == [2, 4, 1, 1, 2, 3, 3]
+    assert all(hg(h, d) * d * 4 <= 256 or hg(h, d) == 1 for h in (2, 4, 8, 16) for d in (8, 16, 32, 64, 128))
+    assert hg(8, 32, 114_615_892, 232_965) == 2          # Reddit shape: edge tensors dominate -> groups
+    assert hg(8, 16, 61_859_140, 2_449_029) == 8         # products shape: node tensors dominate -> no blocking
+    n, e = 4000, 160_000
+    deg = {}
+    for lab in graphs.LABELINGS:
+        g = graphs.chung_lu_graph(n, e, alpha=0.5, seed=1, labeling=lab, community=100)
+        assert g.n_edges == e and int(g.indices_r.max()) < n
+        deg[lab] = (g.indptr_c[1:] - g.indptr_c[:-1]).float()
+        same = ((g.src // 100) == (g.dst // 100)).float().mean()
+        assert (same > 0.85) == (lab == "clustered"), (lab, float(same))
+    # ids sorted by degree: the first tenth of the ids holds far more than a tenth of the slots; shuffled: about a tenth
+    assert float(deg["degree"][: n // 10].sum()) > 0.25 * e and abs(float(deg["shuffled"][: n // 10].sum()) / e - 0.1) < 0.03
+    with __import__("pytest").raises(ValueError):
+        graphs.chung_lu_graph(10, 10, labeling="nope")
